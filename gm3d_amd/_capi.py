@@ -1,0 +1,55 @@
+"""ctypes binding of libgm3d_hip.so -- the C ABI declared in include/gm3d.h.
+
+There is NO CPU fallback anywhere in this package: if the library is missing the
+import fails loudly, and every op rejects non-GPU tensors.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libgm3d_hip.so")
+
+GM3D_OK, GM3D_EINVAL, GM3D_EUNSUPPORTED, GM3D_ELAUNCH = 0, -1, -2, -3
+GM3D_F32, GM3D_BF16 = 0, 1
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes; mirrors include/gm3d.h one to one (tests/test_capi_symbols.py checks it)
+SIGNATURES = {
+    "gm3d_abi_version": [],
+    "gm3d_strerror": [_i],
+    "gm3d_fps": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gm3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gm3d_knn": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_knn_group": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "gm3d_chamfer_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
+    "gm3d_chamfer_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gm3d_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+}
+
+
+class Gm3dError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "gm3d_amd: %s not found. Build it with `python -m gm3d_amd.build` "
+            "(hipcc, --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError = ABI mismatch: fail loudly
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_char_p if name == "gm3d_strerror" else ctypes.c_int
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what):
+    if rc != GM3D_OK:
+        raise Gm3dError("%s failed: %s (code %d)" % (what, lib.gm3d_strerror(rc).decode(), rc))

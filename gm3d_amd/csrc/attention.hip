@@ -1,0 +1,531 @@
+// Multi-head softmax attention (forward + backward) for the Point-MAE token sequences
+// (T <= 64 tokens, head_dim 64, 6 heads) on gfx950 matrix cores.
+//
+// Beneath: timm-0.4.5 Attention.forward -- in-tree twin
+//   Point-MAE_SA3D/models/Point_MAE.py:113-125 (qkv reshape :115, softmax(q k^T * scale) :118-119,
+//   attn @ v :122), used by every Block of TransformerEncoder/TransformerDecoder
+//   (models_mae_learn_loss.py:901-917,959-990).
+//
+// Design (MI355X): a whole (batch, head) problem -- Q,K,V of 64x64 -- fits one CU, so one
+// workgroup owns one (b,h) and nothing but qkv in / out (+lse) ever crosses HBM: the
+// T x T score matrix lives in MFMA accumulators.  Scores are computed TRANSPOSED
+// (S^T = K Q^T) so that a query is a lane and its keys are registers: the softmax row
+// reduction is register-local plus one lane^32 exchange, and the probability tile is
+// already laid out as the A operand of the P.V product (accumulator-as-operand, k order
+// permuted by the C layout).  Two precisions share the structure:
+//   GM3D_BF16: v_mfma_f32_32x32x16_bf16, f32 softmax and accumulation (throughput mode);
+//   GM3D_F32 : v_mfma_f32_32x32x2_f32, bit-exact f32 FMA chains (parity mode).
+// Backward recomputes P from the saved log-sum-exp; each wave owns one 32-key tile for
+// dK/dV and one 32-query tile for dQ, so there are no atomics and no cross-workgroup sums.
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int HD = 64;        // head dim
+constexpr int VLD = 72;       // bf16 LDS row pitch (144 B: 16-B aligned rows)
+
+// C/D layout of a 32x32 MFMA: column = lane & 31, row = crow(reg, lane >> 5).
+__device__ __forceinline__ int crow(int g, int hh) { return (g & 3) + 8 * (g >> 2) + 4 * hh; }
+// k index (0..31) carried by element j of lane half hh at k-step s when accumulator
+// registers 8s..8s+7 are reused as a bf16 operand: equals crow(8s + j, hh).
+__device__ __forceinline__ int permk(int s, int j, int hh) { return 16 * s + 8 * (j >> 2) + 4 * hh + (j & 3); }
+
+__device__ __forceinline__ bf16x8 ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ bf16x8 zero8() {
+    bf16x8 z;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) z[j] = (bf16_t)0.0f;
+    return z;
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) z[g] = 0.f;
+    return z;
+}
+// 8 elements M[row][k], k = permk order of k-step s inside the 32-wide tile starting at k0
+__device__ __forceinline__ bf16x8 ld8_perm(const bf16_t* row, int k0, int s, int hh) {
+    const bf16x4 a = *reinterpret_cast<const bf16x4*>(row + k0 + 16 * s + 4 * hh);
+    const bf16x4 b = *reinterpret_cast<const bf16x4*>(row + k0 + 16 * s + 8 + 4 * hh);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = a[j]; v[4 + j] = b[j]; }
+    return v;
+}
+// 8 elements M[k][col] gathered down a column, k in permk order
+__device__ __forceinline__ bf16x8 ld8_col_perm(const bf16_t* M, int ld, int k0, int s, int hh, int col) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = M[(size_t)(k0 + permk(s, j, hh)) * ld + col];
+    return v;
+}
+__device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (bf16_t)(x[8 * s + j] * mul);
+    return v;
+}
+
+#define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
+
+// Cooperative copy of one head's (T,64) slice of qkv into a zero-padded 64-row LDS tile.
+__device__ __forceinline__ void stage_bf16(bf16_t* dst /*[64][VLD]*/, const bf16_t* src, size_t row_stride, int T) {
+    for (int c = threadIdx.x; c < 64 * 8; c += blockDim.x) {
+        const int row = c >> 3, col = (c & 7) * 8;
+        *reinterpret_cast<bf16x8*>(dst + row * VLD + col) = row < T ? ld8(src + (size_t)row * row_stride + col) : zero8();
+    }
+}
+// f32 tiles use a 64-float pitch with a per-row rotation so that both row-wise and
+// column-wise lane patterns are bank-conflict free: element (r,c) at r*64 + ((c + r) & 63).
+__device__ __forceinline__ int rot(int r, int c) { return r * 64 + ((c + r) & 63); }
+__device__ __forceinline__ void stage_f32(float* dst /*[64*64]*/, const float* src, size_t row_stride, int T) {
+    for (int c = threadIdx.x; c < 64 * 64; c += blockDim.x) {
+        const int row = c >> 6, col = c & 63;
+        dst[rot(row, col)] = row < T ? src[(size_t)row * row_stride + col] : 0.f;
+    }
+}
+
+// ===================================================================== forward, bf16
+__global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                            float* __restrict__ lse, int T, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * VLD];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, qb = threadIdx.x >> 6;  // wave = 32-query block
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD;
+    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    const bf16_t* Kg = Qg + (size_t)H * HD;
+    const bf16_t* Vg = Kg + (size_t)H * HD;
+    const int NK = (T + 31) >> 5;
+
+    stage_bf16(Vs, Vg, rs, T);
+    __syncthreads();
+
+    // S^T tiles: rows = keys (regs), cols = queries (lanes)
+    f32x16 st0 = zero16(), st1 = zero16();
+    const int qrow = 32 * qb + r;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 bq = qrow < T ? ld8(Qg + (size_t)qrow * rs + 16 * s + 8 * hh) : zero8();
+        const bf16x8 a0 = r < T ? ld8(Kg + (size_t)r * rs + 16 * s + 8 * hh) : zero8();
+        st0 = MFMA_BF16(a0, bq, st0);
+        if (NK > 1) {
+            const bf16x8 a1 = 32 + r < T ? ld8(Kg + (size_t)(32 + r) * rs + 16 * s + 8 * hh) : zero8();
+            st1 = MFMA_BF16(a1, bq, st1);
+        }
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int k0 = crow(g, hh);
+        st0[g] = k0 < T ? st0[g] * scale : -INFINITY;
+        st1[g] = 32 + k0 < T ? st1[g] * scale : -INFINITY;
+        m = fmaxf(m, fmaxf(st0[g], st1[g]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        st0[g] = __expf(st0[g] - m);
+        st1[g] = __expf(st1[g] - m);
+        sum += st0[g] + st1[g];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x16 o0 = zero16(), o1 = zero16();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const bf16x8 p0 = cvt8(st0, s, inv);
+        o0 = MFMA_BF16(p0, ld8_col_perm(Vs, VLD, 0, s, hh, r), o0);
+        o1 = MFMA_BF16(p0, ld8_col_perm(Vs, VLD, 0, s, hh, 32 + r), o1);
+        if (NK > 1) {
+            const bf16x8 p1 = cvt8(st1, s, inv);
+            o0 = MFMA_BF16(p1, ld8_col_perm(Vs, VLD, 32, s, hh, r), o0);
+            o1 = MFMA_BF16(p1, ld8_col_perm(Vs, VLD, 32, s, hh, 32 + r), o1);
+        }
+    }
+    // O tile: rows = queries (regs), cols = d (lanes)
+    bf16_t* og = out + (size_t)b * T * H * HD + (size_t)h * HD;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int q = 32 * qb + crow(g, hh);
+        if (q < T) {
+            og[(size_t)q * H * HD + r] = (bf16_t)o0[g];
+            og[(size_t)q * H * HD + 32 + r] = (bf16_t)o1[g];
+        }
+    }
+    if (lse && hh == 0 && qrow < T) lse[((size_t)b * H + h) * T + qrow] = m + logf(sum);
+}
+
+// ===================================================================== forward, f32
+__global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                           float* __restrict__ lse, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;
+    float* Ks = Qs + 64 * 64;
+    float* Vs = Ks + 64 * 64;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int lane = threadIdx.x & 63, qb = threadIdx.x >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD;
+    const float* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    const int NK = (T + 31) >> 5;
+    stage_f32(Qs, Qg, rs, T);
+    stage_f32(Ks, Qg + (size_t)H * HD, rs, T);
+    stage_f32(Vs, Qg + (size_t)2 * H * HD, rs, T);
+    __syncthreads();
+
+    f32x16 st0 = zero16(), st1 = zero16();
+    const int qrow = 32 * qb + r;
+    for (int s = 0; s < 32; ++s) {
+        const int d = 2 * s + hh;
+        const float bq = Qs[rot(qrow, d)];
+        st0 = MFMA_F32(Ks[rot(r, d)], bq, st0);
+        if (NK > 1) st1 = MFMA_F32(Ks[rot(32 + r, d)], bq, st1);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int k0 = crow(g, hh);
+        st0[g] = k0 < T ? st0[g] * scale : -INFINITY;
+        st1[g] = 32 + k0 < T ? st1[g] * scale : -INFINITY;
+        m = fmaxf(m, fmaxf(st0[g], st1[g]));
+    }
+    m = fmaxf(m, __shfl_xor(m, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        st0[g] = expf(st0[g] - m);
+        st1[g] = expf(st1[g] - m);
+        sum += st0[g] + st1[g];
+    }
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.0f / sum;
+
+    f32x16 o0 = zero16(), o1 = zero16();
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {  // k-step s consumes accumulator register s (key crow(s,hh))
+        const int key = crow(s, hh);
+        const float p0 = st0[s] * inv;
+        o0 = MFMA_F32(p0, Vs[rot(key, r)], o0);
+        o1 = MFMA_F32(p0, Vs[rot(key, 32 + r)], o1);
+        if (NK > 1) {
+            const float p1 = st1[s] * inv;
+            o0 = MFMA_F32(p1, Vs[rot(32 + key, r)], o0);
+            o1 = MFMA_F32(p1, Vs[rot(32 + key, 32 + r)], o1);
+        }
+    }
+    float* og = out + (size_t)b * T * H * HD + (size_t)h * HD;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+        const int q = 32 * qb + crow(g, hh);
+        if (q < T) {
+            og[(size_t)q * H * HD + r] = o0[g];
+            og[(size_t)q * H * HD + 32 + r] = o1[g];
+        }
+    }
+    if (lse && hh == 0 && qrow < T) lse[((size_t)b * H + h) * T + qrow] = m + logf(sum);
+}
+
+// ===================================================================== backward, bf16
+// LDS: Q,K,V,dO tiles (64 x VLD bf16 each) + lse[64] + delta[64].
+__global__ __launch_bounds__(128) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                            bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * VLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * VLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * VLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * VLD];
+    __shared__ float Ls[64];
+    __shared__ float Del[64];
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    const bf16_t* Og = out + (size_t)b * T * os + (size_t)h * HD;
+    const bf16_t* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
+    const int NT = (T + 31) >> 5;  // number of 32-row tiles (= waves)
+
+    stage_bf16(Qs, Qg, rs, T);
+    stage_bf16(Ks, Qg + os, rs, T);
+    stage_bf16(Vs, Qg + 2 * os, rs, T);
+    stage_bf16(Ds, Dg, os, T);
+    {   // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
+        const int q = tid >> 1, half = tid & 1;
+        float acc = 0.f;
+        if (q < T) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const bf16x8 o8 = ld8(Og + (size_t)q * os + half * 32 + c * 8);
+                const bf16x8 d8 = ld8(Dg + (size_t)q * os + half * 32 + c * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc += (float)o8[j] * (float)d8[j];
+            }
+        }
+        acc += __shfl_xor(acc, 1);
+        if (half == 0 && q < 64) {
+            Del[q] = acc;
+            Ls[q] = q < T ? lse[((size_t)b * H + h) * T + q] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    bf16_t* dQg = dqkv + (size_t)b * T * rs + (size_t)h * HD;
+    bf16_t* dKg = dQg + os;
+    bf16_t* dVg = dKg + os;
+
+    // ---- phase A: this wave owns key tile kt = w.  Tiles X[q][key]: rows = q (regs), cols = key (lanes).
+    {
+        const int kt = w;
+        const int key = 32 * kt + r;
+        f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int d0 = 16 * ks + 8 * hh;
+                s = MFMA_BF16(ld8(Qs + (32 * qt + r) * VLD + d0), ld8(Ks + key * VLD + d0), s);
+                dp = MFMA_BF16(ld8(Ds + (32 * qt + r) * VLD + d0), ld8(Vs + key * VLD + d0), dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int q = 32 * qt + crow(g, hh);
+                const float p = (q < T && key < T) ? __expf(s[g] * scale - Ls[q]) : 0.f;
+                s[g] = p;                       // P[q][key]
+                dp[g] = p * (dp[g] - Del[q]);   // dS[q][key]
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // sum over q (X rows): X^T . B, B[k=q][col=d]
+                const bf16x8 pa = cvt8(s, ks, 1.0f);
+                const bf16x8 da = cvt8(dp, ks, scale);
+                dv0 = MFMA_BF16(pa, ld8_col_perm(Ds, VLD, 32 * qt, ks, hh, r), dv0);
+                dv1 = MFMA_BF16(pa, ld8_col_perm(Ds, VLD, 32 * qt, ks, hh, 32 + r), dv1);
+                dk0 = MFMA_BF16(da, ld8_col_perm(Qs, VLD, 32 * qt, ks, hh, r), dk0);
+                dk1 = MFMA_BF16(da, ld8_col_perm(Qs, VLD, 32 * qt, ks, hh, 32 + r), dk1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {  // result rows = keys (regs), cols = d (lanes)
+            const int kk = 32 * kt + crow(g, hh);
+            if (kk < T) {
+                dVg[(size_t)kk * rs + r] = (bf16_t)dv0[g];
+                dVg[(size_t)kk * rs + 32 + r] = (bf16_t)dv1[g];
+                dKg[(size_t)kk * rs + r] = (bf16_t)dk0[g];
+                dKg[(size_t)kk * rs + 32 + r] = (bf16_t)dk1[g];
+            }
+        }
+    }
+    // ---- phase B: this wave owns query tile qt = w.  Tiles X'[key][q]: rows = key (regs), cols = q (lanes).
+    {
+        const int qt = w;
+        const int q = 32 * qt + r;
+        const float lq = Ls[q], dq_ = Del[q];
+        f32x16 dq0 = zero16(), dq1 = zero16();
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int d0 = 16 * ks + 8 * hh;
+                s = MFMA_BF16(ld8(Ks + (32 * kt + r) * VLD + d0), ld8(Qs + q * VLD + d0), s);
+                dp = MFMA_BF16(ld8(Vs + (32 * kt + r) * VLD + d0), ld8(Ds + q * VLD + d0), dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int key = 32 * kt + crow(g, hh);
+                const float p = (q < T && key < T) ? __expf(s[g] * scale - lq) : 0.f;
+                dp[g] = p * (dp[g] - dq_);  // dS^T[key][q]
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {  // sum over key (X' rows): X'^T . B, B[k=key][col=d]
+                const bf16x8 da = cvt8(dp, ks, scale);
+                dq0 = MFMA_BF16(da, ld8_col_perm(Ks, VLD, 32 * kt, ks, hh, r), dq0);
+                dq1 = MFMA_BF16(da, ld8_col_perm(Ks, VLD, 32 * kt, ks, hh, 32 + r), dq1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int qq = 32 * qt + crow(g, hh);
+            if (qq < T) {
+                dQg[(size_t)qq * rs + r] = (bf16_t)dq0[g];
+                dQg[(size_t)qq * rs + 32 + r] = (bf16_t)dq1[g];
+            }
+        }
+    }
+}
+
+// ===================================================================== backward, f32
+__global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                           const float* __restrict__ dout, const float* __restrict__ lse,
+                                                           float* __restrict__ dqkv, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* Qs = sm;
+    float* Ks = Qs + 64 * 64;
+    float* Vs = Ks + 64 * 64;
+    float* Ds = Vs + 64 * 64;
+    float* Ls = Ds + 64 * 64;
+    float* Del = Ls + 64;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+    const float* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    const float* Og = out + (size_t)b * T * os + (size_t)h * HD;
+    const float* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
+    const int NT = (T + 31) >> 5;
+
+    stage_f32(Qs, Qg, rs, T);
+    stage_f32(Ks, Qg + os, rs, T);
+    stage_f32(Vs, Qg + 2 * os, rs, T);
+    stage_f32(Ds, Dg, os, T);
+    {
+        const int q = tid >> 1, half = tid & 1;
+        float acc = 0.f;
+        if (q < T)
+            for (int c = 0; c < 32; ++c) acc += Og[(size_t)q * os + half * 32 + c] * Dg[(size_t)q * os + half * 32 + c];
+        acc += __shfl_xor(acc, 1);
+        if (half == 0 && q < 64) {
+            Del[q] = acc;
+            Ls[q] = q < T ? lse[((size_t)b * H + h) * T + q] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    float* dQg = dqkv + (size_t)b * T * rs + (size_t)h * HD;
+    float* dKg = dQg + os;
+    float* dVg = dKg + os;
+
+    {   // phase A: key tile kt = w; X[q][key]
+        const int kt = w;
+        const int key = 32 * kt + r;
+        f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
+        for (int qt = 0; qt < NT; ++qt) {
+            f32x16 s = zero16(), dp = zero16();
+            for (int ks = 0; ks < 32; ++ks) {
+                const int d = 2 * ks + hh;
+                s = MFMA_F32(Qs[rot(32 * qt + r, d)], Ks[rot(key, d)], s);
+                dp = MFMA_F32(Ds[rot(32 * qt + r, d)], Vs[rot(key, d)], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int q = 32 * qt + crow(g, hh);
+                const float p = (q < T && key < T) ? expf(s[g] * scale - Ls[q]) : 0.f;
+                s[g] = p;
+                dp[g] = p * (dp[g] - Del[q]) * scale;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {  // k-step ks consumes register ks: q = 32*qt + crow(ks,hh)
+                const int q = 32 * qt + crow(ks, hh);
+                dv0 = MFMA_F32(s[ks], Ds[rot(q, r)], dv0);
+                dv1 = MFMA_F32(s[ks], Ds[rot(q, 32 + r)], dv1);
+                dk0 = MFMA_F32(dp[ks], Qs[rot(q, r)], dk0);
+                dk1 = MFMA_F32(dp[ks], Qs[rot(q, 32 + r)], dk1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int kk = 32 * kt + crow(g, hh);
+            if (kk < T) {
+                dVg[(size_t)kk * rs + r] = dv0[g];
+                dVg[(size_t)kk * rs + 32 + r] = dv1[g];
+                dKg[(size_t)kk * rs + r] = dk0[g];
+                dKg[(size_t)kk * rs + 32 + r] = dk1[g];
+            }
+        }
+    }
+    {   // phase B: query tile qt = w; X'[key][q]
+        const int qt = w;
+        const int q = 32 * qt + r;
+        const float lq = Ls[q], dq_ = Del[q];
+        f32x16 dq0 = zero16(), dq1 = zero16();
+        for (int kt = 0; kt < NT; ++kt) {
+            f32x16 s = zero16(), dp = zero16();
+            for (int ks = 0; ks < 32; ++ks) {
+                const int d = 2 * ks + hh;
+                s = MFMA_F32(Ks[rot(32 * kt + r, d)], Qs[rot(q, d)], s);
+                dp = MFMA_F32(Vs[rot(32 * kt + r, d)], Ds[rot(q, d)], dp);
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int key = 32 * kt + crow(g, hh);
+                const float p = (q < T && key < T) ? expf(s[g] * scale - lq) : 0.f;
+                dp[g] = p * (dp[g] - dq_) * scale;
+            }
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks) {
+                const int key = 32 * kt + crow(ks, hh);
+                dq0 = MFMA_F32(dp[ks], Ks[rot(key, r)], dq0);
+                dq1 = MFMA_F32(dp[ks], Ks[rot(key, 32 + r)], dq1);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int qq = 32 * qt + crow(g, hh);
+            if (qq < T) {
+                dQg[(size_t)qq * rs + r] = dq0[g];
+                dQg[(size_t)qq * rs + 32 + r] = dq1[g];
+            }
+        }
+    }
+}
+
+static int attn_check(const void* a, const void* b, int B, int T, int H, int dtype) {
+    if (!a || !b || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
+    if (T > 64) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if ((long long)B * H > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
+    return GM3D_OK;
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale,
+                                  int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = attn_check(qkv, out, B, T, H, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int threads = 64 * ((T + 31) / 32);
+    if (dtype == GM3D_BF16) {
+        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(B * H), dim3(threads), 0, st, (const bf16_t*)qkv, (bf16_t*)out,
+                           lse, T, H, scale);
+    } else {
+        const size_t lds = sizeof(float) * 3 * 64 * 64;
+        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(threads), lds, st, (const float*)qkv, (float*)out,
+                           lse, T, H, scale);
+    }
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
+                                  int B, int T, int H, float scale, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = attn_check(qkv, out, B, T, H, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!dout || !lse || !dqkv) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int threads = 64 * ((T + 31) / 32);
+    if (dtype == GM3D_BF16) {
+        hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3(B * H), dim3(threads), 0, st, (const bf16_t*)qkv,
+                           (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale);
+    } else {
+        const size_t lds = sizeof(float) * (4 * 64 * 64 + 128);
+        if (hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return GM3D_ELAUNCH;
+        hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(threads), lds, st, (const float*)qkv,
+                           (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, scale);
+    }
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

@@ -1,0 +1,190 @@
+// Chamfer nearest-neighbour squared-L2 distances (both directions) and their backward
+// for gfx950.
+//
+// Beneath: extensions.chamfer_dist (ChamferDistanceL2/L1) -- reference call sites
+//   Point-MAE_SA3D/models_mae_learn_loss.py:188,407 and models/Point_MAE.py:392-394,426.
+// Algorithm contract: SURVEY.md Appendix B / oracle_chamfer_fwd/bwd (first minimum wins,
+// d=((dx*dx+dy*dy)+dz*dz) fp32 without FMA, backward g=2(x1-x2) scattered to both clouds).
+//
+// Design (MI355X): GM3D calls this with P = B*M = 4992 "clouds" of 32 points
+// (models_mae_learn_loss.py:397-398), so the hot shape gets its own kernel: ONE
+// wavefront per patch, lanes 0-31 own the predicted points and lanes 32-63 the target
+// points; each lane scans the other half through v_readlane broadcasts, so the 32x32
+// pair tile never touches LDS or HBM.  Its backward is atomic-free and deterministic:
+// every lane first forms its own-direction term, then collects the reverse-direction
+// terms whose argmin points at it, in ascending order.
+// Other shapes take an LDS-tiled general kernel (forward) and the upstream-style
+// float-atomic scatter (backward).
+#include "common.hpp"
+
+namespace gm3d {
+
+__device__ __forceinline__ float rl(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+__global__ __launch_bounds__(256) void chamfer32_fwd_kernel(const float* __restrict__ x1,
+                                                            const float* __restrict__ x2, int P,
+                                                            float* __restrict__ d1, float* __restrict__ d2,
+                                                            int32_t* __restrict__ i1, int32_t* __restrict__ i2) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;  // wave-uniform
+    const bool first = lane < 32;
+    const int l = lane & 31;
+    const float* mp = (first ? x1 : x2) + ((size_t)p * 32 + l) * 3;
+    const float mx = mp[0], my = mp[1], mz = mp[2];
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const float ox = first ? rl(mx, 32 + t) : rl(mx, t);
+        const float oy = first ? rl(my, 32 + t) : rl(my, t);
+        const float oz = first ? rl(mz, 32 + t) : rl(mz, t);
+        const float d = sqdist3(mx, my, mz, ox, oy, oz);
+        if (t == 0 || d < best) { best = d; bi = t; }
+    }
+    const size_t o = (size_t)p * 32 + l;
+    if (first) { d1[o] = best; i1[o] = bi; }
+    else { d2[o] = best; i2[o] = bi; }
+}
+
+__global__ __launch_bounds__(256) void chamfer32_bwd_kernel(const float* __restrict__ x1,
+                                                            const float* __restrict__ x2,
+                                                            const int32_t* __restrict__ i1,
+                                                            const int32_t* __restrict__ i2,
+                                                            const float* __restrict__ g1,
+                                                            const float* __restrict__ g2, int P,
+                                                            float* __restrict__ gx1, float* __restrict__ gx2) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const bool first = lane < 32;
+    const int l = lane & 31;
+    const size_t o = (size_t)p * 32 + l;
+    const float* mp = (first ? x1 : x2) + o * 3;
+    const float mx = mp[0], my = mp[1], mz = mp[2];
+    const int j = first ? i1[o] : i2[o];
+    const float* gp = first ? g1 : g2;
+    const float g = gp ? gp[o] : 0.f;
+    // own-direction term: t = 2*(mine - other[j])*g
+    const int src = first ? 32 + j : j;
+    const float ox = __shfl(mx, src), oy = __shfl(my, src), oz = __shfl(mz, src);
+    const float tx = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(mx, ox)), g);
+    const float ty = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(my, oy)), g);
+    const float tz = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(mz, oz)), g);
+    float ax = tx, ay = ty, az = tz;
+    // reverse-direction terms: every point t of the other half whose argmin is me
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int sj = first ? __builtin_amdgcn_readlane(j, 32 + t) : __builtin_amdgcn_readlane(j, t);
+        const float sx = first ? rl(tx, 32 + t) : rl(tx, t);
+        const float sy = first ? rl(ty, 32 + t) : rl(ty, t);
+        const float sz = first ? rl(tz, 32 + t) : rl(tz, t);
+        if (sj == l) { ax = __fsub_rn(ax, sx); ay = __fsub_rn(ay, sy); az = __fsub_rn(az, sz); }
+    }
+    float* out = (first ? gx1 : gx2) + o * 3;
+    out[0] = ax; out[1] = ay; out[2] = az;
+}
+
+// General shapes: thread per point of A, B streamed through LDS in tiles.
+constexpr int CH_TILE = 1024;
+__global__ __launch_bounds__(256) void chamfer_fwd_general_kernel(const float* __restrict__ A,
+                                                                  const float* __restrict__ Bp, int n, int m,
+                                                                  float* __restrict__ dist,
+                                                                  int32_t* __restrict__ idx) {
+    __shared__ float sb[CH_TILE * 3];
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float* a = A + (size_t)p * n * 3;
+    const float* b = Bp + (size_t)p * m * 3;
+    const bool live = i < n;
+    const float mx = live ? a[(size_t)i * 3 + 0] : 0.f;
+    const float my = live ? a[(size_t)i * 3 + 1] : 0.f;
+    const float mz = live ? a[(size_t)i * 3 + 2] : 0.f;
+    float best = sqdist3(mx, my, mz, b[0], b[1], b[2]);  // j == 0 always seeds, as upstream
+    int bi = 0;
+    for (int base = 0; base < m; base += CH_TILE) {
+        const int cnt = min(CH_TILE, m - base);
+        __syncthreads();
+        for (int t = threadIdx.x; t < cnt * 3; t += 256) sb[t] = b[(size_t)base * 3 + t];
+        __syncthreads();
+        for (int t = 0; t < cnt; ++t) {
+            const float d = sqdist3(mx, my, mz, sb[t * 3], sb[t * 3 + 1], sb[t * 3 + 2]);
+            if (d < best) { best = d; bi = base + t; }
+        }
+    }
+    if (live) { dist[(size_t)p * n + i] = best; idx[(size_t)p * n + i] = bi; }
+}
+
+// gA[i] += t, gB[idx[i]] -= t with t = 2*(A[i]-B[idx[i]])*g[i]; outputs pre-zeroed.
+__global__ void chamfer_bwd_general_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
+                                           const int32_t* __restrict__ idx, const float* __restrict__ g,
+                                           int n, int m, float* __restrict__ gA, float* __restrict__ gB) {
+    const int p = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = idx[(size_t)p * n + i];
+    const float gg = g[(size_t)p * n + i];
+    const float* a = A + ((size_t)p * n + i) * 3;
+    const float* b = Bp + ((size_t)p * m + j) * 3;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float t = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(a[d], b[d])), gg);
+        atomicAdd(gA + ((size_t)p * n + i) * 3 + d, t);
+        atomicAdd(gB + ((size_t)p * m + j) * 3 + d, -t);
+    }
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_chamfer_fwd(const float* xyz1, const float* xyz2, int P, int n, int m, float* dist1,
+                                float* dist2, int32_t* idx1, int32_t* idx2, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!xyz1 || !xyz2 || !dist1 || !dist2 || !idx1 || !idx2 || P < 0 || n < 1 || m < 1) return GM3D_EINVAL;
+    if (P == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 32 && m == 32) {
+        hipLaunchKernelGGL(chamfer32_fwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, xyz1, xyz2, P, dist1, dist2,
+                           idx1, idx2);
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
+    if (P > 65535) return GM3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(chamfer_fwd_general_kernel, dim3((n + 255) / 256, P), dim3(256), 0, st, xyz1, xyz2, n, m,
+                       dist1, idx1);
+    GM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(chamfer_fwd_general_kernel, dim3((m + 255) / 256, P), dim3(256), 0, st, xyz2, xyz1, m, n,
+                       dist2, idx2);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_chamfer_bwd(const float* xyz1, const float* xyz2, const int32_t* idx1, const int32_t* idx2,
+                                const float* grad_dist1, const float* grad_dist2, int P, int n, int m,
+                                float* gxyz1, float* gxyz2, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!xyz1 || !xyz2 || !idx1 || !idx2 || !gxyz1 || !gxyz2 || P < 0 || n < 1 || m < 1) return GM3D_EINVAL;
+    if (P == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 32 && m == 32) {
+        hipLaunchKernelGGL(chamfer32_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, xyz1, xyz2, idx1, idx2,
+                           grad_dist1, grad_dist2, P, gxyz1, gxyz2);
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
+    if (P > 65535) return GM3D_EUNSUPPORTED;
+    if (hipMemsetAsync(gxyz1, 0, sizeof(float) * (size_t)P * n * 3, st) != hipSuccess) return GM3D_ELAUNCH;
+    if (hipMemsetAsync(gxyz2, 0, sizeof(float) * (size_t)P * m * 3, st) != hipSuccess) return GM3D_ELAUNCH;
+    if (grad_dist1) {
+        hipLaunchKernelGGL(chamfer_bwd_general_kernel, dim3((n + 255) / 256, P), dim3(256), 0, st, xyz1, xyz2, idx1,
+                           grad_dist1, n, m, gxyz1, gxyz2);
+        GM3D_CHECK_LAUNCH();
+    }
+    if (grad_dist2) {
+        hipLaunchKernelGGL(chamfer_bwd_general_kernel, dim3((m + 255) / 256, P), dim3(256), 0, st, xyz2, xyz1, idx2,
+                           grad_dist2, m, n, gxyz2, gxyz1);
+        GM3D_CHECK_LAUNCH();
+    }
+    return GM3D_OK;
+}

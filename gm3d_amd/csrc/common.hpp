@@ -1,0 +1,56 @@
+// Shared device helpers for the gfx950 kernels (wave64 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gm3d.h"
+
+#define GM3D_WAVE 64
+
+#define GM3D_CHECK_LAUNCH()                                   \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return GM3D_ELAUNCH;           \
+    } while (0)
+
+namespace gm3d {
+
+// Squared distance with the evaluation order fixed by the oracle contract
+// ((dx*dx + dy*dy) + dz*dz, fp32, no FMA).  The translation unit is compiled with
+// -ffp-contract=off; the __f*_rn intrinsics make the intent explicit as well.
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    float dx = __fsub_rn(ax, bx), dy = __fsub_rn(ay, by), dz = __fsub_rn(az, bz);
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+
+// ---- DPP cross-lane moves (gfx9 encodings) -------------------------------------------
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_half_mirror 0x141, row_mirror 0x140,
+// row_bcast15 0x142, row_bcast31 0x143, wave_shr1 0x138.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_u32(unsigned old, unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// Wave-wide max of a 64-bit unsigned key, result broadcast to every lane (as a uniform value).
+__device__ __forceinline__ unsigned long long wave_max_u64(unsigned long long k) {
+#define GM3D_STEP(CTRL, RM)                                                         \
+    {                                                                               \
+        unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);                        \
+        unsigned olo = dpp_u32<CTRL, RM>(lo, lo), ohi = dpp_u32<CTRL, RM>(hi, hi);  \
+        unsigned long long o = ((unsigned long long)ohi << 32) | olo;               \
+        k = o > k ? o : k;                                                          \
+    }
+    GM3D_STEP(0xB1, 0xF)
+    GM3D_STEP(0x4E, 0xF)
+    GM3D_STEP(0x141, 0xF)
+    GM3D_STEP(0x140, 0xF)
+    GM3D_STEP(0x142, 0xA)
+    GM3D_STEP(0x143, 0xC)
+#undef GM3D_STEP
+    unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)k, 63);
+    unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(k >> 32), 63);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+}  // namespace gm3d

@@ -1,0 +1,113 @@
+/*
+ * gm3d.h -- C ABI of libgm3d_hip.so, the MI355X (gfx950) native back end of the
+ * Point-MAE + GeoMask3D pretrain hot path.
+ *
+ * The reference's boundary for this path is Python-level torch ops in three
+ * third-party packages; each entry point below names the
+ * reference interface it sits beneath.  Conventions for every call:
+ *   - plain device pointers + sizes, no torch types; the caller owns every buffer;
+ *   - all tensors are dense row-major ("contiguous") in the stated shape;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream) and the call returns without synchronising;
+ *   - return value GM3D_OK or a negative GM3D_E* code, never throws, no global
+ *     state, thread-compatible; argument/shape errors are detected on the host
+ *     BEFORE any launch (a bad shape never reaches a kernel);
+ *   - inputs are never written.
+ */
+#ifndef GM3D_H
+#define GM3D_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *gm3d_stream_t; /* hipStream_t */
+
+enum {
+    GM3D_OK = 0,
+    GM3D_EINVAL = -1,       /* null pointer / non-positive size / inconsistent shape */
+    GM3D_EUNSUPPORTED = -2, /* shape outside what the kernels are built for */
+    GM3D_ELAUNCH = -3       /* hipLaunchKernel reported an error */
+};
+
+enum { GM3D_F32 = 0, GM3D_BF16 = 1 };
+
+/* ABI version (bumped on any signature change) and error text. */
+int gm3d_abi_version(void);
+const char *gm3d_strerror(int code);
+
+/* Farthest point sampling.
+ * Replaces pointnet2_ops.pointnet2_utils.furthest_point_sample
+ *   (Point-MAE_SA3D/models_mae_learn_loss.py:931, utils/miscc.py:18,
+ *    engine_finetune.py:132, tools/runner_finetune.py:141).
+ * xyz (B,N,3) f32 -> idx (B,npoint) int32; centers (B,npoint,3) f32 optional (NULL
+ * to skip): the gather_operation of :932 fused into the same launch.
+ * Rule: idx[0]=0, running min init 1e10, points with |p|^2<=1e-3 never selected,
+ * argmax ties -> lowest index, d=((dx*dx+dy*dy)+dz*dz) fp32 without FMA.
+ * Limits: 1 <= npoint, N <= 16384. */
+int gm3d_fps(const float *xyz, int B, int N, int npoint, int32_t *idx, float *centers,
+             gm3d_stream_t stream);
+
+/* out[b,c,j] = feat[b,c,idx[b,j]].
+ * Replaces pointnet2_utils.gather_operation forward (models_mae_learn_loss.py:932,
+ * utils/miscc.py:19, engine_finetune.py:134).  feat (B,C,N) f32, idx (B,M) int32. */
+int gm3d_gather_points(const float *feat, const int32_t *idx, int B, int C, int N, int M,
+                       float *out, gm3d_stream_t stream);
+
+/* Backward of gather_operation: grad_feat (B,C,N) is fully written (zero where no
+ * index hits); duplicates accumulate in ascending j (deterministic). */
+int gm3d_gather_points_grad(const float *grad_out, const int32_t *idx, int B, int C, int N, int M,
+                            float *grad_feat, gm3d_stream_t stream);
+
+/* Brute-force k-NN, ascending, ties -> lower reference index.
+ * Replaces knn_cuda.KNN(k, transpose_mode=True)(ref, query)
+ *   (models_mae_learn_loss.py:924,946; models/Point_MAE.py:55,68).
+ * ref (B,N,3), query (B,G,3) f32 -> idx (B,G,k) int64, dist (B,G,k) f32 Euclidean
+ * (sqrt applied) or NULL.  Limits: 1 <= k <= min(N,64), N <= 12288. */
+int gm3d_knn(const float *ref, const float *query, int B, int N, int G, int k,
+             float *dist, int64_t *idx, gm3d_stream_t stream);
+
+/* Fused k-NN + neighbourhood gather + centre subtract = the body of Group.forward
+ * after FPS (models_mae_learn_loss.py:946-957) in one launch.
+ * Outputs: idx (B,G,k) int64 (may be NULL), neighborhood (B,G,k,3) = xyz[idx]-center,
+ * neighborhood_org (B,G,k,3) = xyz[idx] (may be NULL). */
+int gm3d_knn_group(const float *xyz, const float *center, int B, int N, int G, int k,
+                   int64_t *idx, float *neighborhood, float *neighborhood_org,
+                   gm3d_stream_t stream);
+
+/* Chamfer nearest-neighbour squared-L2 distances, both directions, first minimum wins.
+ * Replaces extensions.chamfer_dist forward (ChamferDistanceL2 at
+ * models_mae_learn_loss.py:188,407; models/Point_MAE.py:392-394,426).
+ * xyz1 (P,n,3), xyz2 (P,m,3) f32 -> dist1 (P,n), dist2 (P,m) f32, idx1 (P,n),
+ * idx2 (P,m) int32.  n==m==32 takes the wave-per-patch path. */
+int gm3d_chamfer_fwd(const float *xyz1, const float *xyz2, int P, int n, int m,
+                     float *dist1, float *dist2, int32_t *idx1, int32_t *idx2,
+                     gm3d_stream_t stream);
+
+/* Backward of the above: gxyz1 (P,n,3), gxyz2 (P,m,3) fully written.
+ * grad_dist1/2 may be NULL (treated as zeros).  n==m==32 is atomic-free and
+ * deterministic; other shapes use float atomics like the upstream kernel. */
+int gm3d_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, const int32_t *idx2,
+                     const float *grad_dist1, const float *grad_dist2, int P, int n, int m,
+                     float *gxyz1, float *gxyz2, gm3d_stream_t stream);
+
+/* Multi-head softmax attention core of timm-0.4.5 Attention.forward
+ * (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:113-125): for each (b,h)
+ *   out[b,t,h,:] = softmax(scale * q k^T)[t,:] v
+ * qkv is the (B,T,3,H,64) output of the qkv Linear, out is (B,T,H*64).
+ * dtype GM3D_F32 (exact-f32 MFMA, parity mode) or GM3D_BF16 (bf16 MFMA, f32
+ * softmax/accumulate).  lse (B,H,T) f32 = log-sum-exp of the scaled scores, saved
+ * for backward (may be NULL for inference).  Limits: head_dim == 64, 1 <= T <= 64. */
+int gm3d_attention_fwd(const void *qkv, void *out, float *lse, int B, int T, int H,
+                       float scale, int dtype, gm3d_stream_t stream);
+
+/* Backward: dqkv (B,T,3,H,64) fully written from dout (B,T,H*64), qkv, out, lse. */
+int gm3d_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse,
+                       void *dqkv, int B, int T, int H, float scale, int dtype,
+                       gm3d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GM3D_H */

@@ -1,0 +1,157 @@
+"""Parity of the HIP kernels (through the C ABI) against the CPU oracle.  -m gpu only.
+
+Bar: FPS / KNN / Chamfer-argmin indices bit-exact; Chamfer distances bit-exact (same fp32
+expression); Chamfer gradients and f32 attention within 1e-5 relative; bf16 attention within
+bf16 rounding of an fp32 torch reference (tolerance stated at the assert).
+"""
+import pytest
+import torch
+
+from tests import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gops():
+    from gm3d_amd import ops
+    return ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+@pytest.mark.parametrize("family", list(clouds.FAMILIES))
+@pytest.mark.parametrize("N,G", [(1024, 64), (100, 17), (2048, 128), (300, 300)])
+def test_fps_index_exact(gops, oracle_ops, family, N, G):
+    x = clouds.FAMILIES[family](3, N, seed=11)
+    ref = oracle_ops.furthest_point_sample(x, G)
+    idx, cen = gops.fps(dev(x), G)
+    assert idx.dtype == torch.int32 and idx.shape == (3, G)
+    assert torch.equal(idx.cpu(), ref)
+    exp_cen = torch.gather(x, 1, ref.long().unsqueeze(-1).expand(-1, -1, 3))
+    assert torch.equal(cen.cpu(), exp_cen)
+    # reference-side API: furthest_point_sample + gather_operation (models_mae_learn_loss.py:931-932)
+    idx2 = gops.furthest_point_sample(dev(x), G)
+    got = gops.gather_operation(dev(x).transpose(1, 2).contiguous(), idx2).transpose(1, 2).contiguous()
+    assert torch.equal(got.cpu(), exp_cen)
+
+
+def test_fps_large_cloud(gops, oracle_ops):
+    x = clouds.uniform(1, 8192, seed=5)
+    ref = oracle_ops.furthest_point_sample(x, 1024)
+    assert torch.equal(gops.furthest_point_sample(dev(x), 1024).cpu(), ref)
+    x = clouds.gaussian(1, 16384, seed=6)
+    ref = oracle_ops.furthest_point_sample(x, 64)
+    assert torch.equal(gops.furthest_point_sample(dev(x), 64).cpu(), ref)
+
+
+@pytest.mark.parametrize("family", ["uniform", "gaussian", "lattice", "duplicates"])
+@pytest.mark.parametrize("N,G,k", [(1024, 64, 32), (1024, 128, 16), (1024, 256, 8), (100, 7, 64), (2048, 33, 5)])
+def test_knn_index_exact(gops, oracle_ops, family, N, G, k):
+    x = clouds.FAMILIES[family](2, N, seed=3)
+    fidx = oracle_ops.furthest_point_sample(x, G)
+    center = torch.gather(x, 1, fidx.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    rd, ri = oracle_ops.knn(x, center, k)
+    dist, idx = gops.KNN(k=k, transpose_mode=True)(dev(x), dev(center))
+    assert idx.dtype == torch.int64
+    assert torch.equal(idx.cpu(), ri)
+    assert torch.equal(dist.cpu(), rd)  # sqrt of an identical fp32 value, correctly rounded on both sides
+    rnb, rnbo = oracle_ops.group(x, center, ri)
+    nb, nbo, idx2 = gops.knn_group(dev(x), dev(center), k)
+    assert torch.equal(idx2.cpu(), ri)
+    assert torch.equal(nb.cpu(), rnb) and torch.equal(nbo.cpu(), rnbo)
+
+
+def test_knn_big_cloud(gops, oracle_ops):
+    x = clouds.uniform(1, 8192, seed=9)
+    q = x[:, :40].contiguous()
+    rd, ri = oracle_ops.knn(x, q, 32)
+    dist, idx = gops.knn(dev(x), dev(q), 32)
+    assert torch.equal(idx.cpu(), ri)
+
+
+@pytest.mark.parametrize("P,n,m", [(4992, 32, 32), (7, 32, 32), (5, 50, 70), (2, 1500, 1100), (3, 1, 9)])
+def test_chamfer_forward_backward(gops, oracle_ops, P, n, m):
+    g = torch.Generator().manual_seed(P * 131 + n)
+    a = (torch.rand(P, n, 3, generator=g) - 0.5)
+    b = (torch.rand(P, m, 3, generator=g) - 0.5)
+    if n == m:  # exact duplicates across the two clouds and inside one cloud: argmin ties
+        b[:, :3] = a[:, :3]
+        a[:, 5 % n] = a[:, 4 % n]
+    ga1 = torch.randn(P, n, generator=g)
+    ga2 = torch.randn(P, m, generator=g)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    d1r, d2r, i1r, i2r = oracle_ops.chamfer(ar, br)
+    ((d1r * ga1).sum() + (d2r * ga2).sum()).backward()
+    ag, bg = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    d1, d2, i1, i2 = gops.chamfer(ag, bg)
+    assert torch.equal(i1.cpu(), i1r) and torch.equal(i2.cpu(), i2r)
+    assert torch.equal(d1.cpu(), d1r.detach()) and torch.equal(d2.cpu(), d2r.detach())
+    ((d1 * ga1.cuda()).sum() + (d2 * ga2.cuda()).sum()).backward()
+    # fp32 accumulation order differs from the oracle's fp64 sums: 1e-5 relative to the gradient scale
+    for got, ref in ((ag.grad.cpu(), ar.grad), (bg.grad.cpu(), br.grad)):
+        scale = ref.abs().max().clamp_min(1e-6)
+        assert (got - ref).abs().max() <= 1e-5 * scale
+
+
+def test_chamfer_modules(gops, oracle_ops):
+    g = torch.Generator().manual_seed(1)
+    a, b = torch.rand(64, 32, 3, generator=g), torch.rand(64, 32, 3, generator=g)
+    per_point = gops.ChamferDistanceL2()(dev(a), dev(b))
+    assert per_point.shape == (64, 32)
+    assert torch.equal(per_point.cpu(), oracle_ops.ChamferDistanceL2()(a, b))
+    mean = gops.ChamferDistanceL2(reduction="mean")(dev(a), dev(b))
+    assert abs(mean.item() - oracle_ops.ChamferDistanceL2("mean")(a, b).item()) <= 1e-6
+    l1 = gops.ChamferDistanceL1()(dev(a), dev(b))
+    assert abs(l1.item() - oracle_ops.ChamferDistanceL1()(a, b).item()) <= 1e-6
+
+
+def _attn_ref(qkv, H, scale):
+    B, T, _ = qkv.shape
+    q, k, v = qkv.reshape(B, T, 3, H, 64).permute(2, 0, 3, 1, 4)  # models/Point_MAE.py:115-116
+    attn = ((q @ k.transpose(-2, -1)) * scale).softmax(dim=-1)
+    return (attn @ v).transpose(1, 2).reshape(B, T, H * 64)
+
+
+@pytest.mark.parametrize("T", [64, 25, 39, 1, 32, 33])
+def test_attention_f32(gops, T):
+    torch.manual_seed(T)
+    B, H = 5, 6
+    qkv = (torch.randn(B, T, 3 * H * 64, device="cuda") * 1.5).requires_grad_(True)
+    w = torch.randn(B, T, H * 64, device="cuda")
+    ref = _attn_ref(qkv.double(), H, 0.125)
+    (ref * w.double()).sum().backward()
+    gref = qkv.grad.clone()
+    qkv.grad = None
+    out = gops.attention(qkv, H, 0.125)
+    (out * w).sum().backward()
+    assert (out.double() - ref).abs().max() <= 1e-5 * ref.abs().max()
+    assert (qkv.grad.double() - gref.double()).abs().max() <= 1e-5 * gref.abs().max()
+
+
+@pytest.mark.parametrize("T", [64, 25, 39])
+def test_attention_bf16(gops, T):
+    torch.manual_seed(100 + T)
+    B, H = 4, 6
+    qkv32 = torch.randn(B, T, 3 * H * 64, device="cuda")
+    qkv = qkv32.bfloat16().requires_grad_(True)
+    w = torch.randn(B, T, H * 64, device="cuda").bfloat16()
+    q64 = qkv.detach().double().requires_grad_(True)
+    ref = _attn_ref(q64, H, 0.125)
+    (ref * w.double()).sum().backward()
+    out = gops.attention(qkv, H, 0.125)
+    (out.float() * w.float()).sum().backward()
+    # bf16 has 8 significant bits: P and the outputs are rounded to bf16 -> 2e-2 of the tensor scale
+    assert (out.double() - ref).abs().max() <= 2e-2 * ref.abs().max()
+    assert (qkv.grad.double() - q64.grad).abs().max() <= 3e-2 * q64.grad.abs().max()
+
+
+def test_errors_are_loud(gops):
+    with pytest.raises(RuntimeError):
+        gops.fps(torch.zeros(1, 16, 3), 4)  # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        gops.fps(torch.zeros(1, 3, 16, device="cuda").transpose(1, 2), 4)  # non-contiguous like upstream
+    with pytest.raises(RuntimeError):
+        gops.knn(torch.zeros(1, 8, 3, device="cuda"), torch.zeros(1, 2, 3, device="cuda"), 9)  # k > N
