@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: one Point-MAE + GeoMask3D pretrain step (teacher fwd -> guided mask ->
+student fwd/bwd -> Chamfer + ranking loss -> clip -> AdamW -> EMA) per "step", on synthetic clouds.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]/[2]): B=128 clouds per GPU, N=1024 points, G=64 groups, k=32, d=384,
+depth 12 (+2x4 decoder blocks), bf16 autocast, random-init weights (seed 0), clouds ~ U[-1,1]^3 centred and
+unit-sphere normalised from seed 1234+rank, resident in HBM before the timed region.  One rank per GPU; data
+parallel over clouds, one bucketed RCCL gradient all-reduce per step, weak scaling.
+Rank 0 prints ONE JSON line (see the keys at the bottom); `roofline` is for the hand-written HIP kernel that
+takes the most time in the step, timed with HIP events on its launch stream inside the timed region;
+`cpu_baseline` is the CPU oracle (oracle/, a port -- the reference's own step cannot run on a CPU) timed on
+rank 0's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from types import SimpleNamespace
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense
+
+# SURVEY.md 8(d) per-unit algorithmic figures (bytes unless noted) -> per launch
+def algorithmic(name, meta):
+    """-> (bound, amount per launch, unit) for one launch of a hand-written kernel."""
+    if name == "gm3d_fps":            # 12,288 B xyz + 256 B idx + 768 B centres per cloud
+        return "hbm", meta["B"] * (meta["N"] * 12 + meta["npoint"] * 4 + meta["npoint"] * 12), "B"
+    if name == "gm3d_knn_group":      # xyz + centres in; idx int64 + neighbourhood + neighbourhood_org out
+        g, k = meta["G"], meta["k"]
+        return "hbm", meta["B"] * (meta["N"] * 12 + g * 12 + g * k * 8 + 2 * g * k * 12), "B"
+    if name == "gm3d_chamfer_fwd":    # 2 clouds in, dist1/dist2 + idx1/idx2 out
+        return "hbm", meta["P"] * ((meta["n"] + meta["m"]) * 12 + (meta["n"] + meta["m"]) * 8), "B"
+    if name == "gm3d_chamfer_bwd":    # clouds + idx + grads in, 2 gradient clouds out
+        return "hbm", meta["P"] * ((meta["n"] + meta["m"]) * (12 + 4 + 4 + 12)), "B"
+    if name == "gm3d_attention_fwd":  # QK^T + PV: 4*T^2*64 flop per (b,h)
+        return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
+    if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
+        return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
+    return None
+
+
+def make_clouds(B, N, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(B, N, 3, generator=g) * 2 - 1
+    x = x - x.mean(dim=1, keepdim=True)                        # ShapeNet.pc_norm (datasets/ShapeNet55Dataset.py:45-51)
+    x = x / x.pow(2).sum(-1).sqrt().amax(dim=1, keepdim=True).unsqueeze(-1)
+    return x.to(device).contiguous()
+
+
+def cpu_baseline(batch, steps):
+    """The CPU oracle's pretrain step (fp32, all host threads torch gives us)."""
+    from oracle import model_ref as R
+    from oracle import ops as oracle_ops
+    oracle_ops.build()
+    torch.manual_seed(0)
+    model = R.PointMAEGM3D().train()
+    ema = R.ModelEma(model, 0.999)
+    opt = torch.optim.AdamW(R.param_groups(model, 0.05), lr=1e-3)
+    x = make_clouds(batch, 1024, 1234, "cpu")
+    R.pretrain_step(model, ema, opt, x.clone(), epoch=200, total_epoch=400)       # warm-up
+    t0 = time.time()
+    for _ in range(steps):
+        R.pretrain_step(model, ema, opt, x.clone(), epoch=200, total_epoch=400)
+    dt = time.time() - t0
+    return {"value": batch * steps / dt, "unit": "clouds/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d pretrain steps of B=%d clouds (N=1024,G=64,k=32,d=384,depth=12) fp32, CPU oracle "
+                      "(oracle/model_ref.py + gm3d_oracle.c), %.1f s" % (steps, batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="clouds per GPU (BASELINE config: 128)")
+    ap.add_argument("--fp32", action="store_true", help="parity precision instead of bf16")
+    ap.add_argument("--epoch", type=int, default=200, help="epoch index (200/400: guided-mask branch active)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--bucket-mb", type=int, default=32)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    if args.gpus != world and rank == 0 and world > 1:
+        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    device = torch.device("cuda", local_rank if world > 1 else 0)
+
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import models_mae_learn_loss as M
+    from gm3d_amd import ops
+
+    torch.manual_seed(0)                      # identical random-init weights on every rank
+    model = M.mae_vit_base_patch16_dec512d8b(norm_pix_loss=False).to(device).train()
+    model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
+    optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05)
+    grad_sync = E.GradSync(model.parameters(), bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    step_args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=not args.fp32, accum_iter=1,
+                                lr=1e-3, min_lr=0.0, warmup_epochs=40)
+    torch.manual_seed(1234 + rank)            # per-rank augmentation / mask / DropPath streams
+    pool = [make_clouds(args.batch, 1024, 1234 + rank + 1000 * i, device) for i in range(4)]
+
+    def step(i):
+        E.adjust_learning_rate(optimizer, args.epoch + i / 1000.0, step_args)
+        return E.pretrain_step(model, model_ema, optimizer, pool[i % len(pool)].clone(), args.epoch, step_args,
+                               grad_sync=grad_sync)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up; the first warm-up steps time EVERY hand-written kernel to pick the dominant one
+    probe = ops.KernelTimer()
+    ops.set_kernel_timer(probe)
+    for i in range(max(args.warmup, 1)):
+        out = step(i)
+    ops.set_kernel_timer(None)
+    psum = probe.summary()
+    dominant = max(psum, key=lambda n: psum[n]["total_ms"])
+    timer = ops.KernelTimer(only=[dominant])
+
+    fence()
+    ops.set_kernel_timer(timer)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.set_kernel_timer(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(out["loss"] + out["loss_learn"])
+    assert loss == loss and abs(loss) != float("inf"), "non-finite loss in the timed region"
+
+    if rank == 0:
+        dtype = "f32" if args.fp32 else "bf16"
+        tsum = timer.summary()[dominant]
+        bound, amount, unit = algorithmic(dominant, tsum["meta"])
+        if bound == "hbm":
+            achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS[dtype], "TFLOP/s"
+        per_step = {n: {"launches_per_step": v["launches"] / max(args.warmup, 1),
+                        "avg_us": round(v["avg_ms"] * 1e3, 2),
+                        "ms_per_step": round(v["total_ms"] / max(args.warmup, 1), 4)} for n, v in psum.items()}
+        line = {
+            "metric": "point-clouds/sec pretrain step (N=1024,G=64)",
+            "value": args.batch * world * args.steps / dt,
+            "unit": "clouds/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": dtype,
+            "data": "synthetic",
+            "config": {"workload": "Point-MAE+GM3D pretrain step, B=%d clouds/GPU, N=1024, G=64, k=32, d=384, "
+                                   "depth=12 (+2x4 decoder blocks), mask_ratio 0.6, epoch %d/400 (guided mask), "
+                                   "random-init weights" % (args.batch, args.epoch),
+                       "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
+                         "frac": achieved / peak, "traffic": None,
+                         "avg_launch_us": tsum["avg_ms"] * 1e3, "launches_timed": tsum["launches"],
+                         "algorithmic_per_launch": amount, "algorithmic_unit": unit},
+            "hip_kernels_ms_per_step": per_step,
+            "loss": loss,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,316 @@
+"""Pretrain step engine: teacher -> mask -> student -> losses -> clip/AdamW -> EMA.
+
+Host-side mirror of the reference's Point-MAE_SA3D/engine_pretrain.py::train_one_epoch (P/ below,
+:38-271) with its collaborators: PointcloudScaleAndTranslate (P/datasets/data_transforms.py:20-35),
+lr_sched.adjust_learning_rate (P/util/lr_sched.py:11-23), NativeScalerWithGradNormCount
+(P/util/misc.py:250-276), the AdamW grouping rule (P/tools/builder.py:40-56), timm ModelEma and the
+DDP wrap (P/main_pretrain_multi_gpu.py:296,309-311).
+
+Same results, different execution: nothing in a step synchronises with the host (the reference
+does ~650 tiny H2D/D2H transfers per step at B=128: SURVEY.md 3.1) -- augmentation and mask
+generation are vectorised on the device, losses stay device tensors, the finite-loss guard is a
+device flag read every `print_freq` steps, FPS/KNN run once and are shared by teacher and student
+(identical samples), the teacher skips its unused reconstruction decoder, EMA and AdamW are
+multi-tensor, and only the 36.8 M live gradients are all-reduced (bucketed, overlapped with backward).
+"""
+import math
+import time
+from contextlib import nullcontext
+
+import torch
+import torch.distributed as dist
+
+# --------------------------------------------------------------------------- augmentation
+class PointcloudScaleAndTranslate(object):
+    """P/datasets/data_transforms.py:20-35, vectorised: one (B,3) scale ~ U[lo,hi] and one (B,3) shift ~
+    U[-t,t] drawn on the device, applied in place.  `draws=(scale, shift)` injects the draws (parity tests)."""
+
+    def __init__(self, scale_low=2.0 / 3.0, scale_high=3.0 / 2.0, translate_range=0.2):
+        self.scale_low, self.scale_high, self.translate_range = scale_low, scale_high, translate_range
+
+    def __call__(self, pc, draws=None, generator=None):
+        B = pc.size(0)
+        if draws is None:
+            u = torch.rand(2, B, 3, device=pc.device, generator=generator)
+            scale = u[0] * (self.scale_high - self.scale_low) + self.scale_low
+            shift = (u[1] * 2 - 1) * self.translate_range
+        else:
+            scale, shift = (d.to(pc.device, pc.dtype) for d in draws)
+        pc[:, :, 0:3] = pc[:, :, 0:3] * scale.unsqueeze(1) + shift.unsqueeze(1)
+        return pc
+
+
+train_transforms = PointcloudScaleAndTranslate()
+
+
+# --------------------------------------------------------------------------- lr / optimizer / EMA
+def adjust_learning_rate(optimizer, epoch, args):
+    """Per-iteration linear warm-up then half-cycle cosine (P/util/lr_sched.py:11-23)."""
+    if epoch < args.warmup_epochs:
+        lr = args.lr * epoch / args.warmup_epochs
+    else:
+        lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * \
+            (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+    for group in optimizer.param_groups:
+        new = lr * group["lr_scale"] if "lr_scale" in group else lr
+        if isinstance(group["lr"], torch.Tensor):
+            group["lr"].fill_(new)  # capturable optimizers keep lr on the device
+        else:
+            group["lr"] = new
+    return lr
+
+
+def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
+    """P/tools/builder.py:40-56: no decay for 1-D params, *.bias and any name containing 'token'."""
+    decay, no_decay = [], []
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        if len(param.shape) == 1 or name.endswith(".bias") or "token" in name or name in skip_list:
+            no_decay.append(param)
+        else:
+            decay.append(param)
+    return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
+
+
+def build_optimizer(model, lr=1e-3, weight_decay=0.05, fused=True, capturable=False):
+    groups = add_weight_decay(model, weight_decay=weight_decay)
+    kw = {}
+    if fused and next(model.parameters()).is_cuda:
+        kw["fused"] = True
+    if capturable:
+        kw["capturable"] = True
+        lr = torch.tensor(lr, dtype=torch.float32, device=next(model.parameters()).device)
+    return torch.optim.AdamW(groups, lr=lr, weight_decay=weight_decay, **kw)
+
+
+class ModelEma:
+    """timm-0.4.5 ModelEma: ema = deepcopy(model).eval(), update: v = v*decay + (1-decay)*model_v over
+    every state-dict entry (floating entries as two multi-tensor launches; integer counters copied)."""
+
+    def __init__(self, model, decay=0.9999, device=""):
+        import copy
+        self.ema = copy.deepcopy(model)
+        self.ema.eval()
+        self.decay = decay
+        for p in self.ema.parameters():
+            p.requires_grad_(False)
+        self._pairs = None
+
+    def _build(self, model):
+        msd = model.state_dict()
+        needs_module = any(k.startswith("module.") for k in msd)
+        fe, fm, ie, im = [], [], [], []
+        for k, v in self.ema.state_dict().items():
+            mv = msd["module." + k if needs_module else k]
+            (fe if v.dtype.is_floating_point else ie).append(v)
+            (fm if v.dtype.is_floating_point else im).append(mv)
+        self._pairs = (fe, fm, ie, im)
+
+    @torch.no_grad()
+    def update(self, model):
+        if self._pairs is None:
+            self._build(model)
+        fe, fm, ie, im = self._pairs
+        torch._foreach_mul_(fe, self.decay)
+        torch._foreach_add_(fe, fm, alpha=1.0 - self.decay)
+        for e, m in zip(ie, im):  # num_batches_tracked: v*decay + (1-decay)*m truncates to m's trajectory
+            e.copy_((e * self.decay + (1.0 - self.decay) * m).to(e.dtype))
+
+
+def ema_decay_for_epoch(epoch):
+    """P/engine_pretrain.py:55-60."""
+    return 0.999 + epoch / 100 * (0.9999 - 0.999) if epoch < 100 else 0.9999
+
+
+# --------------------------------------------------------------------------- data-parallel gradient sync
+class GradSync:
+    """Bucketed gradient all-reduce overlapped with backward (the DDP wrap of
+    P/main_pretrain_multi_gpu.py:309-311, rebuilt for RCCL over xGMI).
+
+    Gradients live as views into a few large flat buckets laid out in reverse parameter order
+    (~ the order backward produces them).  A post-accumulate hook counts arrivals; when a bucket is
+    complete its all-reduce is issued asynchronously on the process group's stream while backward keeps
+    running.  xGMI is point-to-point, so a ring all-reduce is per-link bound: few large buckets (default
+    32 MiB -> 5 collectives for the 147 MB of live fp32 gradients) beat DDP's 25 MB default + dead-parameter
+    traffic.  Works on any backend (RCCL on GPUs, gloo in the CPU tests)."""
+
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets = []   # (flat, [params])
+        self._owner = {}
+        cur, cur_bytes = [], 0
+        for p in reversed(self.params):
+            nbytes = p.numel() * 4
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._seal(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._seal(cur)
+        self._pending = [len(ps) for _, ps in self.buckets]
+        self._works = []
+        self._launched = [False] * len(self.buckets)
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        for p in self.params:
+            p.register_post_accumulate_grad_hook(self._hook)
+
+    def _seal(self, ps):
+        n = sum(p.numel() for p in ps)
+        flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+        off = 0
+        for p in ps:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+            self._owner[p] = len(self.buckets)
+        self.buckets.append((flat, ps))
+
+    def zero_grad(self):
+        for flat, _ in self.buckets:
+            flat.zero_()
+        self._pending = [len(ps) for _, ps in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._works = []
+
+    def _launch(self, b):
+        self._launched[b] = True
+        if self.world == 1:
+            return
+        flat = self.buckets[b][0]
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        self._works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), b))
+
+    def _hook(self, p):
+        b = self._owner[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0 and not self._launched[b]:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward: issues any bucket that never completed, waits, averages."""
+        for b in range(len(self.buckets)):
+            if not self._launched[b]:
+                self._launch(b)
+        for work, b in self._works:
+            work.wait()
+            if not self._avg:
+                self.buckets[b][0].div_(self.world)
+        self._works = []
+
+
+def broadcast_buffers(model, src=0, group=None):
+    """DDP's default broadcast_buffers=True: rank 0's BatchNorm running statistics overwrite the other
+    ranks' before the forward pass; one coalesced collective."""
+    bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
+    if not bufs or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([b.reshape(-1) for b in bufs])
+    dist.broadcast(flat, src=src, group=group)
+    off = 0
+    for b in bufs:
+        b.copy_(flat[off:off + b.numel()].view_as(b))
+        off += b.numel()
+
+
+def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
+    """DistributedSampler-style partition (the reference omits the sampler: SURVEY.md 0.6): a seeded
+    permutation per epoch, padded to a multiple of `world`, rank r takes items r, r+world, ..."""
+    g = torch.Generator().manual_seed(seed + epoch)
+    order = torch.randperm(n_items, generator=g) if shuffle else torch.arange(n_items)
+    total = (n_items + world - 1) // world * world
+    if total > n_items:
+        order = torch.cat([order, order[: total - n_items]])
+    return order[rank:total:world]
+
+
+# --------------------------------------------------------------------------- the step
+def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=None, mask_noise=None,
+                  augment=True, aug_draws=None, clip_grad=5.0):
+    """One iteration of P/engine_pretrain.py:77-212.  `samples` (B,N,3) f32 on the GPU (modified in
+    place by the augmentation, like the reference).  Returns device tensors only -- no host sync."""
+    raw = model.module if hasattr(model, "module") else model
+    teacher = model_ema.ema
+    L = raw.num_group
+    len_keep = int(L * (1 - args.mask_ratio))
+    if augment:
+        samples = train_transforms(samples, draws=aug_draws)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
+    B = samples.shape[0]
+    visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
+    with amp:
+        with torch.no_grad():
+            group = teacher.group_divider(samples)  # FPS + KNN once; shared with the student
+            outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False)
+            mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
+                                         total_epoch=args.epochs, noise=mask_noise)
+            bool_masked_pos = mask.flatten(1).to(torch.bool)
+        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group)
+        M = outs["mask_num"]
+        loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"])
+        loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
+        loss = 13.889 * loss_mse + 1.0 * loss_chfr                      # P/:153
+        loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos,
+                                               loss_outs["matrix"].detach(), relative=args.relative)
+    total = (loss + loss_learn) / getattr(args, "accum_iter", 1)         # P/:190,195
+    if grad_sync is not None:
+        grad_sync.zero_grad()
+    else:
+        optimizer.zero_grad(set_to_none=True)
+    total.backward()
+    if grad_sync is not None:
+        grad_sync.finish()
+    grad_norm = torch.nn.utils.clip_grad_norm_(raw.parameters(), clip_grad, foreach=True)  # misc.py:262-264
+    optimizer.step()
+    model_ema.update(raw)
+    return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
+            "loss_mse": loss_mse.detach(), "grad_norm": grad_norm, "mask": bool_masked_pos,
+            "matrix": loss_outs["matrix"].detach(), "teacher_loss_pred": outs_ema["loss_pred"]}
+
+
+def train_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler=None, log_writer=None, args=None,
+                    model_ema=None, model_teacher=None, scheduler=None, optimizer_learn_loss=None,
+                    grad_sync=None, print_freq=20):
+    """Drop-in for P/engine_pretrain.py::train_one_epoch (same positional arguments; `loss_scaler` is
+    accepted for signature compatibility -- bf16/fp32 need no GradScaler).  The data loader yields
+    (B,N,3) float tensors.  Returns the epoch's averaged stats like the reference (:268-271)."""
+    assert args.learning_loss and model_ema is not None, "the north-star path trains with the EMA teacher"
+    model.train(True)
+    model_ema.decay = ema_decay_for_epoch(epoch)
+    n_iter = len(data_loader)
+    sums = None
+    bad = torch.zeros((), dtype=torch.bool, device=device)
+    t0 = time.time()
+    seen = 0
+    for it, points in enumerate(data_loader):
+        lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+        samples = points.to(device, non_blocking=True)
+        out = pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=grad_sync)
+        vec = torch.stack([out["loss"] + out["loss_learn"], out["loss_learn"], out["loss_mse"] * 13.889,
+                           out["loss_chfr"], out["grad_norm"].float()])
+        bad |= ~torch.isfinite(vec).all()
+        sums = vec if sums is None else sums + vec
+        seen += samples.shape[0]
+        if (it + 1) % print_freq == 0 or it + 1 == n_iter:
+            if bool(bad):  # the reference exits on a non-finite loss (:173-175,185-187); one sync per print_freq
+                raise FloatingPointError("non-finite loss in epoch %d near iteration %d" % (epoch, it))
+            cur = (sums / (it + 1)).tolist()
+            if log_writer is not None:
+                step = n_iter * epoch + it
+                for name, v in zip(("train_loss", "train_loss_learn", "train_loss_MSE", "train_loss_Chfr", "grad_norm"), cur):
+                    log_writer.add_scalar(name, v, step)
+                log_writer.add_scalar("lr", lr, step)
+            if not dist.is_initialized() or dist.get_rank() == 0:
+                print("Epoch: [%d]  [%d/%d]  lr %.6f  loss %.4f  loss_learn %.4f  loss_chfr %.4f  grad_norm %.3f  "
+                      "%.0f clouds/s" % (epoch, it + 1, n_iter, lr, cur[0], cur[1], cur[3], cur[4],
+                                         seen / (time.time() - t0)))
+        if it + 1 >= n_iter:
+            break
+    stats = sums / max(n_iter, 1)
+    if dist.is_initialized() and dist.get_world_size() > 1:  # one fused metric all-reduce per epoch
+        dist.all_reduce(stats)
+        stats /= dist.get_world_size()
+    s = stats.tolist()
+    return {"loss": s[0], "loss_learn": s[1], "loss_mse": s[2], "loss_chfr": s[3], "grad_norm": s[4], "lr": lr}

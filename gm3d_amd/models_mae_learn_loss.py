@@ -1,0 +1,377 @@
+"""Point-MAE + GeoMask3D model on the MI355X-native operators.
+
+Host-side mirror of the reference's Point-MAE_SA3D/models_mae_learn_loss.py (P/ below) for the
+pretrain hot path: same class / method names, argument meaning, returned dict keys and
+state-dict key names for every LIVE parameter, so engine_pretrain.py-style callers and the
+fine-tune checkpoint loader (P/main_finetune.py:311-324) work unchanged.  Differences are of
+execution, not of results:
+
+  * FPS, KNN+grouping, Chamfer and the attention core run as hand-written HIP kernels behind the
+    C ABI (gm3d_amd/ops.py); nothing here has a CPU fallback.
+  * the 53.6 M dead image-MAE parameters of the reference (P/:56-94,144-186) are not
+    instantiated -- they never receive a gradient and never influence an output.
+  * boolean-mask gathers (P/:298-299,649-650, host sync) are index gathers with a static visible
+    count; the shared pos_embed MLP is evaluated once for all 64 centres instead of three times;
+    the loss-predictor head's Conv1d(1024,384) + mean(-1) is folded into one 1024-vector product;
+    the mini-PointNet's concat([global,local]) @ W is evaluated as local @ W_l + global @ W_g.
+    Each of these is an exact algebraic identity (fp32 rounding-order differences only).
+"""
+from functools import partial
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .ops import ChamferDistanceL1, ChamferDistanceL2  # noqa: F401  (re-exported like the reference imports)
+
+
+def drop_path(x, p, training):
+    """timm-0.4.5 DropPath: x / keep * floor(keep + U[0,1)), one draw per sample."""
+    if p == 0.0 or not training:
+        return x
+    keep = 1.0 - p
+    m = (keep + torch.rand((x.shape[0],) + (1,) * (x.ndim - 1), dtype=x.dtype, device=x.device)).floor_()
+    return x.div(keep) * m
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+
+class Mlp(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.0):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features or in_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features or in_features, out_features or in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
+class Attention(nn.Module):
+    """timm Attention (in-tree twin P/models/Point_MAE.py:101-125) with the softmax(QK^T)V core on MFMA."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0.0, proj_drop=0.0):
+        super().__init__()
+        if dim // num_heads != 64 or attn_drop != 0.0 or proj_drop != 0.0:
+            raise NotImplementedError("the HIP attention core is built for head_dim 64 without dropout")
+        self.num_heads = num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.proj(ops.attention(self.qkv(x), self.num_heads, self.scale))
+
+
+class Block(nn.Module):
+    def __init__(self, dim, num_heads, mlp_ratio=4.0, qkv_bias=False, qk_scale=None, drop=0.0, attn_drop=0.0,
+                 drop_path=0.0, act_layer=nn.GELU, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                              attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def forward(self, x):
+        x = x + self.drop_path(self.attn(self.norm1(x)))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class Encoder(nn.Module):
+    """mini-PointNet token embed (P/:868-899).  Parameters keep the Conv1d/BatchNorm1d layout and names
+    (encoder.first_conv.{0,1,3}, encoder.second_conv.{0,1,3}); the math runs on a (rows, channels)
+    layout so no transposes are materialised."""
+
+    def __init__(self, encoder_channel):
+        super().__init__()
+        self.encoder_channel = encoder_channel
+        self.first_conv = nn.Sequential(nn.Conv1d(3, 128, 1), nn.BatchNorm1d(128), nn.ReLU(inplace=True),
+                                        nn.Conv1d(128, 256, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
+                                         nn.Conv1d(512, self.encoder_channel, 1))
+
+    def forward(self, point_groups):
+        bs, g, n, _ = point_groups.shape
+        c0, bn0, _, c1 = self.first_conv
+        c2, bn1, _, c3 = self.second_conv
+        x = point_groups.reshape(bs * g * n, 3)
+        h = F.relu(bn0(F.linear(x, c0.weight.squeeze(-1), c0.bias)))
+        f = F.linear(h, c1.weight.squeeze(-1), c1.bias)                      # (rows, 256)
+        fg = f.view(bs * g, n, 256).amax(dim=1)                              # (groups, 256)
+        w2 = c2.weight.squeeze(-1)                                           # [:, :256] global | [:, 256:] local
+        y = F.linear(f, w2[:, 256:]).view(bs * g, n, 512) + F.linear(fg, w2[:, :256], c2.bias).unsqueeze(1)
+        y = F.relu(bn1(y.view(bs * g * n, 512)))
+        z = F.linear(y, c3.weight.squeeze(-1), c3.bias).view(bs * g, n, self.encoder_channel).amax(dim=1)
+        return z.view(bs, g, self.encoder_channel)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, embed_dim=768, depth=4, num_heads=12, mlp_ratio=4.0, qkv_bias=False, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.0):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+
+    def forward(self, x, pos):
+        for block in self.blocks:  # pos is re-added before EVERY block (P/:914-917)
+            x = block(x + pos)
+        return x
+
+
+class TransformerDecoder(nn.Module):
+    def __init__(self, embed_dim=384, depth=4, num_heads=6, mlp_ratio=4.0, qkv_bias=False, qk_scale=None,
+                 drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.blocks = nn.ModuleList([
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale,
+                  drop=drop_rate, attn_drop=attn_drop_rate,
+                  drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.head = nn.Identity()
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):  # P/:975-982
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def forward(self, x, pos, return_token_num):
+        for block in self.blocks:
+            x = block(x + pos)
+        return self.head(self.norm(x))  # ALL tokens, like P/:989
+
+
+class Group(nn.Module):
+    """FPS + KNN grouping (P/:919-957): one FPS launch (centres gathered in-kernel) and one fused
+    KNN + gather + centre-subtract launch."""
+
+    def __init__(self, num_group, group_size):
+        super().__init__()
+        self.num_group = num_group
+        self.group_size = group_size
+        self.knn = ops.KNN(k=self.group_size, transpose_mode=True)
+
+    def fps(self, data, number):
+        """data (B,N,3) -> sampled points (B,number,3) (P/:926-933)."""
+        return ops.fps(data.contiguous(), number)[1]
+
+    def forward(self, xyz):
+        xyz = xyz.contiguous()
+        center = self.fps(xyz, self.num_group)
+        neighborhood, neighborhood_org, idx = ops.knn_group(xyz, center, self.group_size, return_idx=True)
+        assert idx.size(1) == self.num_group and idx.size(2) == self.group_size
+        return neighborhood, center, neighborhood_org
+
+
+def split_ids(mask, num_visible=None):
+    """(B,L) bool -> (ids of visible tokens, ids of masked tokens), each in original index order:
+    the order boolean-mask indexing produces at P/:298-299,649-650."""
+    if num_visible is None:
+        num_visible = int((~mask[0]).sum())  # host sync; the engine passes the static count instead
+    ids = torch.argsort(mask.to(torch.uint8), dim=1, stable=True)
+    return ids[:, :num_visible], ids[:, num_visible:]
+
+
+def take(x, ids):
+    """x (B,L,...) gathered along dim 1 by ids (B,K)."""
+    tail = x.shape[2:]
+    ix = ids.reshape(ids.shape + (1,) * len(tail)).expand(ids.shape + tail)
+    return torch.gather(x, 1, ix)
+
+
+class MaskedAutoencoderViT(nn.Module):
+    """GM3D Point-MAE (P/:30-188 live part).  The image-MAE constructor arguments are accepted and
+    ignored, exactly as the reference ignores them for the point-cloud path (hyper-parameters are the
+    literals of P/:110-117)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=1024, depth=24, num_heads=16,
+                 decoder_embed_dim=512, decoder_depth=8, decoder_num_heads=16, mlp_ratio=4.0,
+                 norm_layer=nn.LayerNorm, norm_pix_loss=False, asymmetric_decoder=False, mask_ratio=0.75,
+                 vis_mask_ratio=0.0, saliency=False):
+        super().__init__()
+        self.norm_pix_loss = norm_pix_loss
+        self.vis_mask_ratio = vis_mask_ratio
+        self.encoder_dims = 384
+        self.trans_dim = 384
+        self.depth = 12
+        self.drop_path_rate = 0.1
+        self.num_heads = 6
+        self.group_size = 32
+        self.decoder_depth = 4
+        self.decoder_num_heads = 6
+        self.num_group = 64
+
+        self.encoder = Encoder(encoder_channel=self.encoder_dims)
+        self.pos_embed = nn.Sequential(nn.Linear(3, 128), nn.GELU(), nn.Linear(128, 384))
+        dpr = [x.item() for x in torch.linspace(0, self.drop_path_rate, self.depth)]
+        self.blocks = TransformerEncoder(embed_dim=self.trans_dim, depth=self.depth, drop_path_rate=dpr,
+                                         num_heads=self.num_heads)
+        # both decoders take the FIRST four entries of the 12-long list (P/:119,129,135)
+        self.MAE_decoder = TransformerDecoder(embed_dim=self.trans_dim, depth=self.decoder_depth,
+                                              drop_path_rate=dpr, num_heads=self.decoder_num_heads)
+        self.MAE_decoder_loss_pred = TransformerDecoder(embed_dim=self.trans_dim, depth=self.decoder_depth,
+                                                        drop_path_rate=dpr, num_heads=self.decoder_num_heads)
+        self.norm_p = nn.LayerNorm(self.trans_dim)
+        self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, self.trans_dim))
+        self.increase_dim_2 = nn.Sequential(nn.Conv1d(self.trans_dim, 1024, 1), nn.BatchNorm1d(1024),
+                                            nn.LeakyReLU(negative_slope=0.2),
+                                            nn.Conv1d(1024, self.trans_dim, 1, bias=True))
+        self.increase_dim_just_network_without_feature = nn.Sequential(
+            nn.Conv1d(self.trans_dim, 3 * self.group_size, 1, bias=True))
+        self.loss_func = ChamferDistanceL2()
+
+    # ------------------------------------------------------------------ forward pieces
+    def _encode_visible(self, neighborhood, vis_ids, pos_all):
+        tokens = self.encoder(neighborhood)  # B G C
+        x_vis = self.blocks(take(tokens, vis_ids), take(pos_all, vis_ids))
+        return self.norm_p(x_vis)
+
+    def forward_encoder_point(self, neighborhood, center, mask, num_visible=None):
+        """P/:293-306: embed -> keep visible tokens -> pos -> 12 blocks -> norm_p."""
+        vis_ids, _ = split_ids(mask, num_visible)
+        return self._encode_visible(neighborhood, vis_ids, self.pos_embed(center))
+
+    def _loss_pred_head(self, x):
+        """increase_dim_2 then mean over channels (P/:668,677): Conv1d(384,1024) -> BN1d -> LeakyReLU ->
+        [Conv1d(1024,384) ; mean(-1)] with the last two folded into one 1024-vector."""
+        c0, bn, act, c1 = self.increase_dim_2
+        B, L, C = x.shape
+        h = act(bn(F.linear(x.reshape(B * L, C), c0.weight.squeeze(-1), c0.bias)))
+        w = c1.weight.squeeze(-1).mean(dim=0)
+        return (F.linear(h, w.unsqueeze(0)).squeeze(-1) + c1.bias.mean()).view(B, L)
+
+    def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True):
+        """pts (B,N,3) f32, mask (B,64) bool (True = masked).  Extra keyword-only conveniences for the
+        engine: `num_visible` (static visible count, avoids a host sync), `group` (a previously
+        computed (neighborhood, center, neighborhood_org), e.g. the teacher's -- the student sees the
+        identical samples), `need_pix_pred=False` (skip the reconstruction decoder whose output the
+        teacher pass never reads, P/engine_pretrain.py:86-94)."""
+        neighborhood, center, neighborhood_org = group if group is not None else self.group_divider(pts)
+        vis_ids, mask_ids = split_ids(mask, num_visible)
+        pos_all = self.pos_embed(center)
+        x_vis = self._encode_visible(neighborhood, vis_ids, pos_all)
+        B, _, C = x_vis.shape
+        if noaug:
+            return x_vis
+        N = mask_ids.shape[1]
+        x_full = torch.cat([x_vis, self.mask_token.expand(B, N, -1).to(x_vis.dtype)], dim=1)
+        pos_full = torch.cat([take(pos_all, vis_ids), take(pos_all, mask_ids)], dim=1)
+
+        rebuild_points = None
+        if need_pix_pred:
+            x_rec = self.MAE_decoder(x_full, pos_full, N)
+            c = self.increase_dim_just_network_without_feature[0]
+            rebuild_points = F.linear(x_rec, c.weight.squeeze(-1), c.bias)  # B L 96
+        loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
+        return {
+            "pix_pred": rebuild_points,
+            "mask": mask,
+            "mask_num": N,
+            "features": x_vis,
+            "loss_pred": self._loss_pred_head(loss_pred_),
+            "neighborhood": neighborhood,
+            "neighborhood_org": neighborhood_org,
+            "center": center,
+        }
+
+    def forward_loss(self, pred, target, mask):
+        """pred (B,M,96) = pix_pred[:, -M:], target = neighborhood (B,64,32,3), mask (B,64) bool (P/:384-412)."""
+        N, t, n, D = target.shape
+        M = pred.shape[1]
+        _, mask_ids = split_ids(mask, t - M)
+        target = take(target, mask_ids).reshape(-1, n, D).to(torch.float32)
+        pred = pred.reshape(-1, n, D).to(torch.float32)
+        loss = self.loss_func(pred, target).reshape(N, -1, n)
+        mean = loss.mean()
+        return {"MSE_mean": mean * 0.0, "Chamfer_mean": mean, "matrix": loss.mean(dim=-1)}
+
+    @torch.no_grad()
+    def generate_mask(self, loss_pred, mask_ratio=0.75, images=None, guide=True, epoch=0, total_epoch=200,
+                      noise=None):
+        """Teacher-guided mask (P/:744-784), vectorised on device, no host sync.
+        The `len_loss` tokens with the highest predicted loss are always masked; the other
+        L-len_loss tokens are ranked by `noise` (default: fresh U[0,1) draws, which is the uniform
+        random permutation np.random.shuffle produces at P/:773) and the first len_keep stay visible.
+        Returns float (B,L), 0 = keep, 1 = remove, like the reference."""
+        N, L = loss_pred.shape
+        len_keep = int(L * (1 - mask_ratio))
+        keep_ratio = float((epoch + 1) / total_epoch) * 0.5 if guide else 0.5
+        len_loss = int((L - len_keep) * keep_ratio)
+        if noise is None:
+            noise = torch.rand(N, L, device=loss_pred.device)
+        else:
+            noise = noise.to(loss_pred.device, torch.float32).clone()
+        if len_loss > 0:
+            forced = torch.argsort(loss_pred.float(), dim=1)[:, L - len_loss:]
+            noise.scatter_(1, forced, float("inf"))
+        keep = torch.argsort(noise, dim=1)[:, :len_keep]
+        mask = torch.ones(N, L, device=loss_pred.device)
+        mask.scatter_(1, keep, 0.0)
+        return mask
+
+    def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False):
+        """P/:786-815.  relative=True: pairwise ranking BCE over masked tokens."""
+        loss_pred = loss_pred.float()
+        loss_target = loss_target.float()
+        if relative:
+            pos = loss_target.unsqueeze(1) > loss_target.unsqueeze(2)
+            neg = loss_target.unsqueeze(1) < loss_target.unsqueeze(2)
+            sig = torch.sigmoid(loss_pred.unsqueeze(1) - loss_pred.unsqueeze(2))
+            loss = -pos.to(sig.dtype) * torch.log(sig + 1e-6) - neg.to(sig.dtype) * torch.log(1 - sig + 1e-6)
+            return loss.sum() / (pos | neg).sum()
+        mean = loss_target.mean(dim=1, keepdim=True)
+        var = loss_target.var(dim=1, keepdim=True)
+        return ((loss_pred - (loss_target - mean) / (var + 1.0e-6) ** 0.5) ** 2).mean()
+
+    # ------------------------------------------------------------------ checkpoints
+    def load_reference_state_dict(self, state_dict):
+        """Load a reference checkpoint's `state_dict`/`model` entry: live keys must all be present and
+        match; the reference's dead image-MAE keys (patch_embed.*, decoder_*, increase_dim.*, ...) are
+        ignored.  Returns the list of ignored keys."""
+        sd = {k[len("module."):] if k.startswith("module.") else k: v for k, v in state_dict.items()}
+        own = self.state_dict()
+        missing = [k for k in own if k not in sd]
+        if missing:
+            raise KeyError("reference checkpoint lacks live keys: %s" % missing[:5])
+        self.load_state_dict({k: sd[k] for k in own}, strict=True)
+        return sorted(k for k in sd if k not in own)
+
+
+def mae_vit_base_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=768, depth=12, num_heads=12, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_large_patch16_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=16, embed_dim=1024, depth=24, num_heads=16, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+def mae_vit_huge_patch14_dec512d8b(**kwargs):
+    return MaskedAutoencoderViT(patch_size=14, embed_dim=1280, depth=32, num_heads=16, decoder_embed_dim=512,
+                                decoder_depth=8, decoder_num_heads=16, mlp_ratio=4,
+                                norm_layer=partial(nn.LayerNorm, eps=1e-6), **kwargs)
+
+
+Point_MAE = MaskedAutoencoderViT  # north-star surface name

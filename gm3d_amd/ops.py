@@ -21,6 +21,49 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events recorded on the stream the kernels are launched on
+    (torch's current stream).  bench.py installs one over its timed region for the roofline figures;
+    when none is installed the wrappers add nothing.  `only` restricts timing to some kernel names."""
+
+    def __init__(self, only=None):
+        self.only = set(only) if only else None
+        self.records = {}   # name -> [(start_event, end_event, meta)]
+
+    def wants(self, name):
+        return self.only is None or name in self.only
+
+    def summary(self):
+        """name -> {"launches", "avg_ms", "total_ms", "meta"} (synchronises)."""
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = [s.elapsed_time(e) for s, e, _ in recs]
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "meta": recs[0][2]}
+        return out
+
+
+_timer = None
+
+
+def set_kernel_timer(timer):
+    global _timer
+    _timer = timer
+
+
+def _launch(name, meta, fn, *args):
+    """Call one C-ABI entry point, check its status, optionally bracket it with HIP events."""
+    t = _timer
+    if t is None or not t.wants(name):
+        check(fn(*args), name)
+        return
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    check(fn(*args), name)
+    e.record()
+    t.records.setdefault(name, []).append((s, e, meta))
+
+
 def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -45,7 +88,7 @@ def fps(xyz, npoint, return_centers=True):
     B, N, _ = xyz.shape
     idx = torch.empty(B, npoint, dtype=torch.int32, device=xyz.device)
     cen = torch.empty(B, npoint, 3, dtype=torch.float32, device=xyz.device) if return_centers else None
-    check(lib.gm3d_fps(_ptr(xyz), B, N, int(npoint), _ptr(idx), _ptr(cen), _stream()), "gm3d_fps")
+    _launch("gm3d_fps", {"B": B, "N": N, "npoint": int(npoint)}, lib.gm3d_fps, _ptr(xyz), B, N, int(npoint), _ptr(idx), _ptr(cen), _stream())
     return idx, cen
 
 
@@ -63,8 +106,7 @@ class _GatherOperation(torch.autograd.Function):
         B, C, N = features.shape
         M = idx.size(1)
         out = torch.empty(B, C, M, dtype=torch.float32, device=features.device)
-        check(lib.gm3d_gather_points(_ptr(features), _ptr(idx), B, C, N, M, _ptr(out), _stream()),
-              "gm3d_gather_points")
+        _launch("gm3d_gather_points", {"B": B, "C": C, "N": N, "M": M}, lib.gm3d_gather_points, _ptr(features), _ptr(idx), B, C, N, M, _ptr(out), _stream())
         ctx.save_for_backward(idx)
         ctx.N = N
         ctx.mark_non_differentiable(idx)
@@ -76,8 +118,7 @@ class _GatherOperation(torch.autograd.Function):
         g = grad_out.contiguous().float()
         B, C, M = g.shape
         gf = torch.empty(B, C, ctx.N, dtype=torch.float32, device=g.device)
-        check(lib.gm3d_gather_points_grad(_ptr(g), _ptr(idx), B, C, ctx.N, M, _ptr(gf), _stream()),
-              "gm3d_gather_points_grad")
+        _launch("gm3d_gather_points_grad", {"B": B, "C": C, "N": ctx.N, "M": M}, lib.gm3d_gather_points_grad, _ptr(g), _ptr(idx), B, C, ctx.N, M, _ptr(gf), _stream())
         return gf, None
 
 
@@ -98,7 +139,7 @@ def knn(ref, query, k, return_dist=True):
     G = query.size(1)
     idx = torch.empty(B, G, k, dtype=torch.int64, device=ref.device)
     dist = torch.empty(B, G, k, dtype=torch.float32, device=ref.device) if return_dist else None
-    check(lib.gm3d_knn(_ptr(ref), _ptr(query), B, N, G, int(k), _ptr(dist), _ptr(idx), _stream()), "gm3d_knn")
+    _launch("gm3d_knn", {"B": B, "N": N, "G": G, "k": int(k)}, lib.gm3d_knn, _ptr(ref), _ptr(query), B, N, G, int(k), _ptr(dist), _ptr(idx), _stream())
     return dist, idx
 
 
@@ -134,8 +175,7 @@ def knn_group(xyz, center, k, return_idx=True, return_org=True):
     nb = torch.empty(B, G, k, 3, dtype=torch.float32, device=dev)
     nbo = torch.empty(B, G, k, 3, dtype=torch.float32, device=dev) if return_org else None
     idx = torch.empty(B, G, k, dtype=torch.int64, device=dev) if return_idx else None
-    check(lib.gm3d_knn_group(_ptr(xyz), _ptr(center), B, N, G, int(k), _ptr(idx), _ptr(nb), _ptr(nbo), _stream()),
-          "gm3d_knn_group")
+    _launch("gm3d_knn_group", {"B": B, "N": N, "G": G, "k": int(k)}, lib.gm3d_knn_group, _ptr(xyz), _ptr(center), B, N, G, int(k), _ptr(idx), _ptr(nb), _ptr(nbo), _stream())
     return nb, nbo, idx
 
 
@@ -156,8 +196,7 @@ class _Chamfer(torch.autograd.Function):
         d2 = torch.empty(P, m, dtype=torch.float32, device=dev)
         i1 = torch.empty(P, n, dtype=torch.int32, device=dev)
         i2 = torch.empty(P, m, dtype=torch.int32, device=dev)
-        check(lib.gm3d_chamfer_fwd(_ptr(a), _ptr(b), P, n, m, _ptr(d1), _ptr(d2), _ptr(i1), _ptr(i2), _stream()),
-              "gm3d_chamfer_fwd")
+        _launch("gm3d_chamfer_fwd", {"P": P, "n": n, "m": m}, lib.gm3d_chamfer_fwd, _ptr(a), _ptr(b), P, n, m, _ptr(d1), _ptr(d2), _ptr(i1), _ptr(i2), _stream())
         ctx.save_for_backward(a, b, i1, i2)
         ctx.mark_non_differentiable(i1, i2)
         return d1, d2, i1, i2
@@ -171,8 +210,8 @@ class _Chamfer(torch.autograd.Function):
         g2 = g2.contiguous().float() if g2 is not None else None
         ga = torch.empty_like(a)
         gb = torch.empty_like(b)
-        check(lib.gm3d_chamfer_bwd(_ptr(a), _ptr(b), _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), P, n, m,
-                                   _ptr(ga), _ptr(gb), _stream()), "gm3d_chamfer_bwd")
+        _launch("gm3d_chamfer_bwd", {"P": P, "n": n, "m": m}, lib.gm3d_chamfer_bwd, _ptr(a), _ptr(b), _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), P, n, m,
+                                   _ptr(ga), _ptr(gb), _stream())
         return ga, gb
 
 
@@ -237,8 +276,8 @@ class _Attention(torch.autograd.Function):
             raise RuntimeError("qkv last dim must be 3*num_heads*64")
         out = torch.empty(B, T, num_heads * 64, dtype=qkv.dtype, device=qkv.device)
         lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=qkv.device)
-        check(lib.gm3d_attention_fwd(_ptr(qkv), _ptr(out), _ptr(lse), B, T, num_heads, float(scale),
-                                     _DT[qkv.dtype], _stream()), "gm3d_attention_fwd")
+        _launch("gm3d_attention_fwd", {"B": B, "T": T, "H": num_heads, "dtype": str(qkv.dtype)}, lib.gm3d_attention_fwd, _ptr(qkv), _ptr(out), _ptr(lse), B, T, num_heads, float(scale),
+                                     _DT[qkv.dtype], _stream())
         ctx.save_for_backward(qkv, out, lse)
         ctx.num_heads, ctx.scale = num_heads, float(scale)
         return out
@@ -249,8 +288,8 @@ class _Attention(torch.autograd.Function):
         dout = dout.contiguous().to(qkv.dtype)
         B, T, _ = qkv.shape
         dqkv = torch.empty_like(qkv)
-        check(lib.gm3d_attention_bwd(_ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, ctx.num_heads,
-                                     ctx.scale, _DT[qkv.dtype], _stream()), "gm3d_attention_bwd")
+        _launch("gm3d_attention_bwd", {"B": B, "T": T, "H": ctx.num_heads, "dtype": str(qkv.dtype)}, lib.gm3d_attention_bwd, _ptr(qkv), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, ctx.num_heads,
+                                     ctx.scale, _DT[qkv.dtype], _stream())
         return dqkv, None, None
 
 

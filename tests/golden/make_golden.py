@@ -61,7 +61,7 @@ def install_absent_packages():
 
 
 def npy(t):
-    return t.detach().cpu().numpy()
+    return t.detach().cpu().numpy().copy()  # copy: buffers are restored in place later
 
 
 def main():
