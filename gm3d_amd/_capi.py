@@ -27,6 +27,13 @@ SIGNATURES = {
     "gm3d_chamfer_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "gm3d_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gm3d_residual_ln_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_residual_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_ln_partial_rows": [_i],
+    "gm3d_colsum_finish": [_vp, _i, _i, _i, _vp, _i, _vp],
+    "gm3d_bias_gelu_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_bias_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_gelu_partial_rows": [_i],
 }
 
 

@@ -21,6 +21,7 @@ SOURCES = {
     "knn.hip": ["-ffp-contract=off"],
     "chamfer.hip": ["-ffp-contract=off"],
     "attention.hip": [],
+    "rowops.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

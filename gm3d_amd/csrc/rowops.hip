@@ -1,0 +1,358 @@
+// Row-wise fused kernels around the transformer-block GEMMs (gfx950): residual + bias + DropPath +
+// positional add + LayerNorm in one pass (forward and backward), and bias + exact-erf GELU (forward
+// and backward), with the bias / gamma / beta gradient column sums folded into the backward passes.
+//
+// Beneath: timm-0.4.5 Block.forward -- in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146 --
+//   x = x + drop_path(attn(norm1(x)));  x = x + drop_path(mlp(norm2(x)))
+// as driven by TransformerEncoder/Decoder.forward (models_mae_learn_loss.py:914-917,984-990:
+//   x = block(x + pos) for every block, then a final LayerNorm), Mlp (Point_MAE.py:82-98: fc1, GELU, fc2).
+//
+// Why these exist (MI355X): the round-1 profile of the PyTorch op chain spends 12 of 28.8 ms per step in
+// ~1700 tiny launches (dtype casts, adds, LayerNorm, GELU, bias-grad reductions).  Every one of them is a
+// streaming pass over a (rows, 384|1536) tile; fusing them around the GEMMs leaves ONE HBM pass between
+// two GEMMs.  The residual stream stays fp32; GEMM operands are `T` (bf16 in throughput mode, f32 in
+// parity mode).  One wavefront owns one row (384 = 64 lanes x 6 columns): the row statistics are DPP wave
+// reductions, no LDS, no barrier on the forward path.
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 bf16_t;
+constexpr int LNC = 384;            // model width (trans_dim, models_mae_learn_loss.py:110)
+constexpr int LN_PER_LANE = 6;      // 3 pairs per lane: columns 2*lane + 128*i + {0,1}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#define GM3D_SUM_STEP(CTRL, RM) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xF, false));
+    GM3D_SUM_STEP(0xB1, 0xF)   // quad_perm [1,0,3,2]
+    GM3D_SUM_STEP(0x4E, 0xF)   // quad_perm [2,3,0,1]
+    GM3D_SUM_STEP(0x141, 0xF)  // row_half_mirror
+    GM3D_SUM_STEP(0x140, 0xF)  // row_mirror
+    GM3D_SUM_STEP(0x142, 0xA)  // row_bcast15 -> rows 1,3
+    GM3D_SUM_STEP(0x143, 0xC)  // row_bcast31 -> rows 2,3
+#undef GM3D_SUM_STEP
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+template <class T> struct Pair;
+template <> struct Pair<float> {
+    static __device__ __forceinline__ void load(const float* p, float& a, float& b) {
+        const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y;
+    }
+    static __device__ __forceinline__ void store(float* p, float a, float b) {
+        *reinterpret_cast<float2*>(p) = make_float2(a, b);
+    }
+};
+template <> struct Pair<bf16_t> {
+    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
+    static __device__ __forceinline__ void load(const bf16_t* p, float& a, float& b) {
+        const v2 v = *reinterpret_cast<const v2*>(p); a = (float)v[0]; b = (float)v[1];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
+        v2 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; *reinterpret_cast<v2*>(p) = v;
+    }
+};
+
+// out_res = res + rowscale[r / rows_per_sample] * (y + bias) + add ;  h = LayerNorm(out_res) * gamma + beta
+// res/out_res fp32; y, add, h are T; any of y / bias / rowscale / add / out_res may be null.
+template <class T>
+__global__ __launch_bounds__(256) void residual_ln_fwd_kernel(const float* __restrict__ res, const T* __restrict__ y,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ rowscale, int rows_per_sample,
+                                                              const T* __restrict__ add, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ out_res, T* __restrict__ h,
+                                                              float* __restrict__ mean, float* __restrict__ rstd, int R) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * 4;
+    for (int r = wave; r < R; r += nwaves) {
+        const size_t base = (size_t)r * LNC;
+        const float rs = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
+        float v[LN_PER_LANE];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = 2 * lane + 128 * i;
+            float a = 0.f, b = 0.f;
+            if (res) Pair<float>::load(res + base + c, a, b);
+            if (y) {
+                float ya, yb;
+                Pair<T>::load(y + base + c, ya, yb);
+                if (bias) { ya += bias[c]; yb += bias[c + 1]; }
+                a += rs * ya; b += rs * yb;
+            }
+            if (add) {
+                float pa, pb;
+                Pair<T>::load(add + base + c, pa, pb);
+                a += pa; b += pb;
+            }
+            v[2 * i] = a; v[2 * i + 1] = b;
+            if (out_res) Pair<float>::store(out_res + base + c, a, b);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_PER_LANE; ++i) s += v[i];
+        const float mu = wave_sum(s) * (1.0f / LNC);
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_PER_LANE; ++i) { const float d = v[i] - mu; q += d * d; }
+        const float rsd = rsqrtf(wave_sum(q) * (1.0f / LNC) + eps);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = 2 * lane + 128 * i;
+            Pair<T>::store(h + base + c, (v[2 * i] - mu) * rsd * gamma[c] + beta[c],
+                           (v[2 * i + 1] - mu) * rsd * gamma[c + 1] + beta[c + 1]);
+        }
+        if (lane == 0) { mean[r] = mu; rstd[r] = rsd; }
+    }
+}
+
+// Backward of the above for one LayerNorm site.
+//   xhat = (x - mean) * rstd,  g = dh * gamma
+//   dx   = gin + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))          (grad wrt out_res)
+//   dy   = rowscale * dx  (T, optional)      acc += dx (fp32, optional: positional-embedding grad)
+//   partial[wg][0][c] = sum_rows dh * xhat (dgamma), [1] = sum_rows dh (dbeta), [2] = sum_rows dy (dbias)
+template <class T>
+__global__ __launch_bounds__(256) void residual_ln_bwd_kernel(const T* __restrict__ dh, const float* __restrict__ gin,
+                                                              const float* __restrict__ x, const float* __restrict__ mean,
+                                                              const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                              const float* __restrict__ rowscale, int rows_per_sample,
+                                                              float* __restrict__ dx, T* __restrict__ dy,
+                                                              float* __restrict__ acc, float* __restrict__ partial, int R) {
+    __shared__ float red[3][4][LNC];
+    const int lane = threadIdx.x & 63;
+    const int w = threadIdx.x >> 6;
+    const int wave = blockIdx.x * 4 + w;
+    const int nwaves = gridDim.x * 4;
+    float sg[LN_PER_LANE], sb[LN_PER_LANE], sy[LN_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < LN_PER_LANE; ++i) sg[i] = sb[i] = sy[i] = 0.f;
+    float gm[LN_PER_LANE];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { gm[2 * i] = gamma[2 * lane + 128 * i]; gm[2 * i + 1] = gamma[2 * lane + 128 * i + 1]; }
+
+    for (int r = wave; r < R; r += nwaves) {
+        const size_t base = (size_t)r * LNC;
+        const float mu = mean[r], rsd = rstd[r];
+        const float rs = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
+        float d[LN_PER_LANE], xh[LN_PER_LANE];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = 2 * lane + 128 * i;
+            float xa, xb;
+            Pair<T>::load(dh + base + c, d[2 * i], d[2 * i + 1]);
+            Pair<float>::load(x + base + c, xa, xb);
+            xh[2 * i] = (xa - mu) * rsd; xh[2 * i + 1] = (xb - mu) * rsd;
+        }
+#pragma unroll
+        for (int i = 0; i < LN_PER_LANE; ++i) {
+            sg[i] += d[i] * xh[i];
+            sb[i] += d[i];
+            const float g = d[i] * gm[i];
+            s1 += g; s2 += g * xh[i];
+        }
+        const float m1 = wave_sum(s1) * (1.0f / LNC), m2 = wave_sum(s2) * (1.0f / LNC);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int c = 2 * lane + 128 * i;
+            float a = rsd * (d[2 * i] * gm[2 * i] - m1 - xh[2 * i] * m2);
+            float b = rsd * (d[2 * i + 1] * gm[2 * i + 1] - m1 - xh[2 * i + 1] * m2);
+            if (gin) { float ga, gb; Pair<float>::load(gin + base + c, ga, gb); a += ga; b += gb; }
+            Pair<float>::store(dx + base + c, a, b);
+            if (acc) { float pa, pb; Pair<float>::load(acc + base + c, pa, pb); Pair<float>::store(acc + base + c, pa + a, pb + b); }
+            if (dy) {
+                const float ya = rs * a, yb = rs * b;
+                Pair<T>::store(dy + base + c, ya, yb);
+                sy[2 * i] += ya; sy[2 * i + 1] += yb;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 2 * lane + 128 * i;
+        red[0][w][c] = sg[2 * i]; red[0][w][c + 1] = sg[2 * i + 1];
+        red[1][w][c] = sb[2 * i]; red[1][w][c + 1] = sb[2 * i + 1];
+        red[2][w][c] = sy[2 * i]; red[2][w][c + 1] = sy[2 * i + 1];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 3 * LNC; t += 256) {
+        const int k = t / LNC, c = t - k * LNC;
+        partial[((size_t)blockIdx.x * 3 + k) * LNC + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
+    }
+}
+
+// out[c] (+)= sum over `nrows` partial rows (row pitch `pitch` floats).
+// Block = 32 columns x 8 row slices: every thread streams nrows/8 independent loads (coalesced across the
+// 32 columns), then the 8 slices meet in LDS.  (A one-thread-per-column loop is a ~1000-deep dependent
+// load chain: 178 us per call in the first profile.)
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ partial, int nrows, int pitch,
+                                                            int ncols, float* __restrict__ out, int accumulate) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < ncols) {
+        int r = slice;
+        for (; r + 24 < nrows; r += 32) {
+            s0 += partial[(size_t)r * pitch + c];
+            s1 += partial[(size_t)(r + 8) * pitch + c];
+            s2 += partial[(size_t)(r + 16) * pitch + c];
+            s3 += partial[(size_t)(r + 24) * pitch + c];
+        }
+        for (; r < nrows; r += 8) s0 += partial[(size_t)r * pitch + c];
+    }
+    red[slice][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (slice == 0 && c < ncols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cx];
+        out[c] = accumulate ? out[c] + s : s;
+    }
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// g = GELU(f + bias), exact erf form (nn.GELU default).  C % 8 == 0; one thread = 8 consecutive columns.
+template <class T>
+__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ f, const float* __restrict__ bias,
+                                                            T* __restrict__ g, int R, int C) {
+    const int cpr = C >> 3;  // 8-column chunks per row
+    const size_t total = (size_t)R * cpr;
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(t % cpr) * 8;
+        const size_t o = (t / cpr) * (size_t)C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float a, b;
+            Pair<T>::load(f + o + 2 * i, a, b);
+            a += bias[c + 2 * i]; b += bias[c + 2 * i + 1];
+            Pair<T>::store(g + o + 2 * i, gelu_f(a), gelu_f(b));
+        }
+    }
+}
+
+// df = dg * GELU'(f + bias); partial[blockIdx][c] = sum over this block's rows of df (bias gradient).
+// blockDim = C/8 threads: thread t owns columns 8t..8t+7 for every row the block visits.
+template <class T>
+__global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ f, const float* __restrict__ bias,
+                                     T* __restrict__ df, float* __restrict__ partial, int R, int C) {
+    const int c = threadIdx.x * 8;
+    float bv[8], s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { bv[i] = bias[c + i]; s[i] = 0.f; }
+    for (int r = blockIdx.x; r < R; r += gridDim.x) {
+        const size_t o = (size_t)r * C + c;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float fa, fb, ga, gb;
+            Pair<T>::load(f + o + 2 * i, fa, fb);
+            Pair<T>::load(dg + o + 2 * i, ga, gb);
+            const float da = ga * gelu_grad_f(fa + bv[2 * i]), db = gb * gelu_grad_f(fb + bv[2 * i + 1]);
+            Pair<T>::store(df + o + 2 * i, da, db);
+            s[2 * i] += da; s[2 * i + 1] += db;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) partial[(size_t)blockIdx.x * C + c + i] = s[i];
+}
+
+static inline int ln_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 512 ? 512 : g); }
+static inline int gelu_bwd_grid(int R) { return R < 256 ? R : 256; }
+
+}  // namespace gm3d
+
+extern "C" int gm3d_ln_partial_rows(int R) { return R < 1 ? 0 : gm3d::ln_grid(R); }
+extern "C" int gm3d_gelu_partial_rows(int R) { return R < 1 ? 0 : gm3d::gelu_bwd_grid(R); }
+
+extern "C" int gm3d_residual_ln_fwd(const float* res, const void* y, const float* bias, const float* rowscale,
+                                    int rows_per_sample, const void* add, const float* gamma, const float* beta,
+                                    float eps, float* out_res, void* h, float* mean, float* rstd, int R, int C,
+                                    int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!gamma || !beta || !h || !mean || !rstd || R < 0 || (!res && !y && !add)) return GM3D_EINVAL;
+    if (rowscale && rows_per_sample < 1) return GM3D_EINVAL;
+    if (C != LNC) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(residual_ln_fwd_kernel<bf16_t>, dim3(ln_grid(R)), dim3(256), 0, st, res, (const bf16_t*)y, bias,
+                           rowscale, rows_per_sample, (const bf16_t*)add, gamma, beta, eps, out_res, (bf16_t*)h, mean, rstd, R);
+    else
+        hipLaunchKernelGGL(residual_ln_fwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, res, (const float*)y, bias,
+                           rowscale, rows_per_sample, (const float*)add, gamma, beta, eps, out_res, (float*)h, mean, rstd, R);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_residual_ln_bwd(const void* dh, const float* gin, const float* x, const float* mean,
+                                    const float* rstd, const float* gamma, const float* rowscale, int rows_per_sample,
+                                    float* dx, void* dy, float* acc, float* partial, int R, int C, int dtype,
+                                    gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dh || !x || !mean || !rstd || !gamma || !dx || !partial || R < 0) return GM3D_EINVAL;
+    if (rowscale && rows_per_sample < 1) return GM3D_EINVAL;
+    if (C != LNC) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(residual_ln_bwd_kernel<bf16_t>, dim3(ln_grid(R)), dim3(256), 0, st, (const bf16_t*)dh, gin, x, mean,
+                           rstd, gamma, rowscale, rows_per_sample, dx, (bf16_t*)dy, acc, partial, R);
+    else
+        hipLaunchKernelGGL(residual_ln_bwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, (const float*)dh, gin, x, mean,
+                           rstd, gamma, rowscale, rows_per_sample, dx, (float*)dy, acc, partial, R);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_colsum_finish(const float* partial, int nrows, int pitch, int ncols, float* out, int accumulate,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!partial || !out || nrows < 0 || ncols < 1 || pitch < ncols) return GM3D_EINVAL;
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows,
+                       pitch, ncols, out, accumulate);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bias_gelu_fwd(const void* f, const float* bias, void* g, int R, int C, int dtype,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!f || !bias || !g || R < 0 || C < 8) return GM3D_EINVAL;
+    if (C % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    const size_t total = (size_t)R * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)f, bias, (bf16_t*)g, R, C);
+    else
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f, bias, (float*)g, R, C);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bias_gelu_bwd(const void* dg, const void* f, const float* bias, void* df, float* partial, int R,
+                                  int C, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dg || !f || !bias || !df || !partial || R < 0 || C < 8) return GM3D_EINVAL;
+    if (C % 8 || C / 8 > 1024) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(bias_gelu_bwd_kernel<bf16_t>, dim3(gelu_bwd_grid(R)), dim3(C / 8), 0, st, (const bf16_t*)dg,
+                           (const bf16_t*)f, bias, (bf16_t*)df, partial, R, C);
+    else
+        hipLaunchKernelGGL(bias_gelu_bwd_kernel<float>, dim3(gelu_bwd_grid(R)), dim3(C / 8), 0, st, (const float*)dg,
+                           (const float*)f, bias, (float*)df, partial, R, C);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

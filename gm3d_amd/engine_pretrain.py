@@ -85,8 +85,10 @@ def build_optimizer(model, lr=1e-3, weight_decay=0.05, fused=True, capturable=Fa
 
 
 class ModelEma:
-    """timm-0.4.5 ModelEma: ema = deepcopy(model).eval(), update: v = v*decay + (1-decay)*model_v over
-    every state-dict entry (floating entries as two multi-tensor launches; integer counters copied)."""
+    """timm-0.4.5 ModelEma: ema = deepcopy(model).eval(), update: v = v*decay + (1-decay)*model_v over every
+    state-dict entry (floating entries as two multi-tensor launches; integer counters -- BatchNorm
+    num_batches_tracked -- follow the same formula with truncation, like timm).  `decay` is a host float: a
+    captured hipGraph bakes it in, so GraphedPretrainStep is re-captured when the epoch schedule changes it."""
 
     def __init__(self, model, decay=0.9999, device=""):
         import copy
@@ -114,7 +116,7 @@ class ModelEma:
         fe, fm, ie, im = self._pairs
         torch._foreach_mul_(fe, self.decay)
         torch._foreach_add_(fe, fm, alpha=1.0 - self.decay)
-        for e, m in zip(ie, im):  # num_batches_tracked: v*decay + (1-decay)*m truncates to m's trajectory
+        for e, m in zip(ie, im):
             e.copy_((e * self.decay + (1.0 - self.decay) * m).to(e.dtype))
 
 
@@ -237,6 +239,11 @@ def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=N
     len_keep = int(L * (1 - args.mask_ratio))
     if augment:
         samples = train_transforms(samples, draws=aug_draws)
+    if getattr(args, "bf16", False):
+        from .fused import weight_cache
+        weight_cache.pin(raw)        # no-ops after the first call
+        weight_cache.pin(teacher)
+        weight_cache.refresh()       # ONE multi-tensor cast of all GEMM weights per model per step
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
     B = samples.shape[0]
     visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
@@ -268,6 +275,38 @@ def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=N
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
             "loss_mse": loss_mse.detach(), "grad_norm": grad_norm, "mask": bool_masked_pos,
             "matrix": loss_outs["matrix"].detach(), "teacher_loss_pred": outs_ema["loss_pred"]}
+
+
+class GraphedPretrainStep:
+    """The whole pretrain step captured once as a hipGraph and replayed (single-GPU): the step is ~1300
+    launches, so the host cannot keep the GPU fed in eager mode.  Everything that changes between steps is
+    device state the captured kernels read: the input batch (copied into a static buffer), the learning rate
+    (optimizer built with capturable=True keeps it in a tensor), RNG offsets (graph-safe philox).  `epoch` and
+    the EMA decay are baked in at capture: re-capture (~4 step times) when the epoch changes them.
+
+    CAUTION (ROCm 7.2 / torch 2.10): PyTorch's multi-block reduce_kernel (sum/mean over >~64k elements, column
+    sums over thousands of rows) returns stale results from the second replay on when graph-pool memory is
+    reused -- reproduced without any of our code by tools/graph_reduce_test2.py.  The step is only replay-safe
+    where every such reduction is one of our own kernels; tests/test_gpu_graph.py compares replay against eager."""
+
+    def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3):
+        self.static_in = example.clone()
+        self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                pretrain_step(model, model_ema, optimizer, self.static_in.clone(), epoch, args)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args)
+
+    def __call__(self, samples):
+        self.static_in.copy_(samples, non_blocking=True)
+        self.graph.replay()
+        return self.out
 
 
 def train_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler=None, log_writer=None, args=None,

@@ -1,0 +1,274 @@
+"""Fused transformer stack: the blocks of TransformerEncoder / TransformerDecoder plus their final LayerNorm
+as ONE autograd node with a hand-written forward and backward.
+
+Restates, operation for operation, timm-0.4.5 Block (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:82-146)
+as driven by P/models_mae_learn_loss.py:914-917 and :984-990:
+
+    for block in blocks:  x = block(x + pos)        # x += dp(attn(LN1(x)));  x += dp(mlp(LN2(x)))
+    return LayerNorm(x)
+
+Per block the forward is 4 GEMMs (hipBLASLt via torch.mm on cached bf16 weights), the MFMA attention kernel and
+3 row-wise HIP passes (gm3d_amd/csrc/rowops.hip): [residual + bias + DropPath + pos + LayerNorm] x2 and
+[bias + GELU]; the backward is 8 GEMMs, the attention backward and 3 row-wise passes that also produce every
+bias / gamma / beta gradient as fused column sums.  The residual stream is fp32, GEMM operands are bf16
+(throughput mode) or fp32 (parity mode: same code path, checked to 1e-5 against the reference fixtures).
+"""
+import ctypes
+
+import torch
+
+from . import _capi
+from ._capi import lib
+from .ops import _launch, _ptr, _stream, _DT
+
+LNC = 384
+
+
+# ----------------------------------------------------------------------------- bf16 weight cache
+class _WeightCache:
+    """bf16 copies of the 2-D fp32 master weights for the GEMMs.
+
+    * `pin(model)` / `refresh()`: persistent bf16 buffers for every >=2-D parameter of a model, re-cast by ONE
+      multi-tensor launch (the engine calls refresh() once per step for student and teacher; autocast re-casts
+      ~400 times per step).  Under hipGraph capture this is the only mode that is correct: the refresh launch is
+      part of the captured step, and get() involves no host-side staleness decision.
+    * un-pinned weights: cached per (storage, version counter); re-cast when the master changed; never cached
+      while a stream capture is running."""
+
+    def __init__(self):
+        self._c = {}
+        self._pinned = {}      # data_ptr -> bf16 buffer
+        self._groups = []      # (fp32 list, bf16 list)
+
+    def pin(self, model, dtype=torch.bfloat16):
+        src = [p for p in model.parameters() if p.dim() >= 2 and p.dtype == torch.float32 and p.is_cuda
+               and p.data_ptr() not in self._pinned]
+        if not src:
+            return
+        dst = [torch.empty_like(p, dtype=dtype) for p in src]
+        for p, d in zip(src, dst):
+            self._pinned[p.data_ptr()] = d
+        self._groups.append(([p.detach() for p in src], dst))
+        with torch.no_grad():
+            torch._foreach_copy_(dst, self._groups[-1][0])
+
+    def refresh(self):
+        with torch.no_grad():
+            for src, dst in self._groups:
+                torch._foreach_copy_(dst, src)
+
+    def get(self, w, dtype):
+        if w.dtype == dtype:
+            return w
+        hit = self._pinned.get(w.data_ptr())
+        if hit is not None and hit.dtype == dtype and hit.shape == w.shape:
+            return hit
+        if torch.cuda.is_current_stream_capturing():
+            return w.detach().to(dtype)
+        key = (w.data_ptr(), dtype, tuple(w.shape))
+        hit = self._c.get(key)
+        if hit is not None and hit[0] == w._version:
+            return hit[1]
+        with torch.no_grad():
+            c = w.detach().to(dtype)
+        self._c[key] = (w._version, c)
+        return c
+
+
+weight_cache = _WeightCache()
+
+
+# ----------------------------------------------------------------------------- row-op wrappers
+def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, eps, adt, R, want_res=True):
+    dev = gamma.device
+    out_res = torch.empty(R, LNC, dtype=torch.float32, device=dev) if want_res else None
+    h = torch.empty(R, LNC, dtype=adt, device=dev)
+    mean = torch.empty(R, dtype=torch.float32, device=dev)
+    rstd = torch.empty(R, dtype=torch.float32, device=dev)
+    _launch("gm3d_residual_ln_fwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_fwd, _ptr(res), _ptr(y), _ptr(bias),
+            _ptr(rowscale), int(rows_per_sample), _ptr(add), _ptr(gamma), _ptr(beta), float(eps), _ptr(out_res), _ptr(h),
+            _ptr(mean), _ptr(rstd), R, LNC, _DT[adt], _stream())
+    return out_res, h, mean, rstd
+
+
+def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R):
+    """-> dx (R,C) f32, dy (R,C) adt | None, sums (3,C) f32 = [dgamma, dbeta, colsum(dy)]."""
+    dev = gamma.device
+    dx = torch.empty(R, LNC, dtype=torch.float32, device=dev)
+    dy = torch.empty(R, LNC, dtype=adt, device=dev) if want_dy else None
+    nrows = lib.gm3d_ln_partial_rows(R)
+    partial = torch.empty(nrows, 3 * LNC, dtype=torch.float32, device=dev)
+    _launch("gm3d_residual_ln_bwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_bwd, _ptr(dh), _ptr(gin), _ptr(x),
+            _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rowscale), int(rows_per_sample), _ptr(dx), _ptr(dy), _ptr(acc),
+            _ptr(partial), R, LNC, _DT[adt], _stream())
+    sums = torch.empty(3, LNC, dtype=torch.float32, device=dev)
+    _launch("gm3d_colsum_finish", {"rows": nrows, "cols": 3 * LNC}, lib.gm3d_colsum_finish, _ptr(partial), nrows, 3 * LNC,
+            3 * LNC, _ptr(sums), 0, _stream())
+    return dx, dy, sums
+
+
+def bias_gelu_fwd(f, bias, adt):
+    R, C = f.shape
+    g = torch.empty_like(f)
+    _launch("gm3d_bias_gelu_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_bias_gelu_fwd, _ptr(f), _ptr(bias), _ptr(g),
+            R, C, _DT[adt], _stream())
+    return g
+
+
+def bias_gelu_bwd(dg, f, bias, adt):
+    """-> df (R,C) adt, dbias (C) f32."""
+    R, C = f.shape
+    df = torch.empty_like(f)
+    nrows = lib.gm3d_gelu_partial_rows(R)
+    partial = torch.empty(nrows, C, dtype=torch.float32, device=f.device)
+    _launch("gm3d_bias_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_bias_gelu_bwd, _ptr(dg), _ptr(f), _ptr(bias),
+            _ptr(df), _ptr(partial), R, C, _DT[adt], _stream())
+    db = torch.empty(C, dtype=torch.float32, device=f.device)
+    _launch("gm3d_colsum_finish", {"rows": nrows, "cols": C}, lib.gm3d_colsum_finish, _ptr(partial), nrows, C, C, _ptr(db), 0,
+            _stream())
+    return df, db
+
+
+def _attention_fwd(qkv, B, T, H, scale):
+    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    _launch("gm3d_attention_fwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_fwd, _ptr(qkv),
+            _ptr(out), _ptr(lse), B, T, H, float(scale), _DT[qkv.dtype], _stream())
+    return out, lse
+
+
+def _attention_bwd(qkv, out, dout, lse, B, T, H, scale):
+    dqkv = torch.empty_like(qkv)
+    _launch("gm3d_attention_bwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_bwd, _ptr(qkv),
+            _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, H, float(scale), _DT[qkv.dtype], _stream())
+    return dqkv
+
+
+def _wgrad(dy, x):
+    """dW = dy^T @ x accumulated in fp32, returned fp32 (master-weight gradient)."""
+    if dy.dtype == torch.float32:
+        return dy.t() @ x
+    try:
+        return torch.mm(dy.t(), x, out_dtype=torch.float32)
+    except TypeError:
+        return (dy.t() @ x).float()
+
+
+PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
+
+
+def block_params(block):
+    return [block.norm1.weight, block.norm1.bias, block.attn.qkv.weight, block.attn.proj.weight, block.attn.proj.bias,
+            block.norm2.weight, block.norm2.bias, block.mlp.fc1.weight, block.mlp.fc1.bias, block.mlp.fc2.weight,
+            block.mlp.fc2.bias]
+
+
+class TransformerStackFn(torch.autograd.Function):
+    """args: x (B,T,C), pos (B,T,C), meta, final_w, final_b, then PER_BLOCK tensors per block.
+    meta: dict(num_heads, scale, eps, final_eps, adt, dp=[(scale_attn|None, scale_mlp|None) per block])."""
+
+    @staticmethod
+    def forward(ctx, x, pos, meta, final_w, final_b, *params):
+        with torch.autocast("cuda", enabled=False):
+            return TransformerStackFn._forward(ctx, x, pos, meta, final_w, final_b, *params)
+
+    @staticmethod
+    def _forward(ctx, x, pos, meta, final_w, final_b, *params):
+        B, T, C = x.shape
+        assert C == LNC and len(params) % PER_BLOCK == 0
+        nblk = len(params) // PER_BLOCK
+        adt, H, scale, eps = meta["adt"], meta["num_heads"], meta["scale"], meta["eps"]
+        R = B * T
+        res = x.reshape(R, C).float().contiguous()
+        posa = pos.reshape(R, C).to(adt).contiguous()
+        need = any(ctx.needs_input_grad)   # (forward runs with grad mode off; this is the reliable signal)
+        y = bias = rs = None
+        saved = []
+        for i in range(nblk):
+            ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
+            dp1, dp2 = meta["dp"][i]
+            u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R)
+            qkv = h1 @ weight_cache.get(wqkv, adt).t()
+            a, lse = _attention_fwd(qkv, B, T, H, scale)
+            p = a @ weight_cache.get(wproj, adt).t()
+            x1, h2, m2, r2 = residual_ln_fwd(u, p, bproj, dp1, T, None, ln2w, ln2b, eps, adt, R)
+            f = h2 @ weight_cache.get(w1, adt).t()
+            g = bias_gelu_fwd(f, b1, adt)
+            o = g @ weight_cache.get(w2, adt).t()
+            if need:
+                saved += [u, h1, m1, r1, qkv, a, lse, x1, h2, m2, r2, f, g]
+            res, y, bias, rs = x1, o, b2, dp2
+        xf, hout, mf, rf = residual_ln_fwd(res, y, bias, rs, T, None, final_w, final_b, meta["final_eps"], adt, R,
+                                           want_res=need)
+        if need:
+            ctx.save_for_backward(final_w, xf, mf, rf, *params, *saved)
+        ctx.meta, ctx.shape, ctx.nblk = meta, (B, T, C), nblk
+        ctx.in_dtypes = (x.dtype, pos.dtype)
+        return hout.view(B, T, C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.autocast("cuda", enabled=False):
+            return TransformerStackFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
+        meta, (B, T, C), nblk = ctx.meta, ctx.shape, ctx.nblk
+        adt, H, scale = meta["adt"], meta["num_heads"], meta["scale"]
+        R = B * T
+        tens = ctx.saved_tensors
+        final_w, xf, mf, rf = tens[:4]
+        params = tens[4:4 + nblk * PER_BLOCK]
+        saved = tens[4 + nblk * PER_BLOCK:]
+        grads = [None] * (nblk * PER_BLOCK)
+        dh = dout.reshape(R, C).to(adt).contiguous()
+        dp2_last = meta["dp"][nblk - 1][1]
+        G, d_o, sums = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R)
+        g_final_w, g_final_b, db2 = sums[0], sums[1], sums[2]
+        dpos = torch.zeros(R, C, dtype=torch.float32, device=dout.device)
+        for i in range(nblk - 1, -1, -1):
+            ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
+            u, h1, m1, r1, qkv, a, lse, x1, h2, m2, r2, f, g = saved[i * 13:(i + 1) * 13]
+            dp1 = meta["dp"][i][0]
+            dp2_prev = meta["dp"][i - 1][1] if i > 0 else None
+            gi = grads[i * PER_BLOCK:(i + 1) * PER_BLOCK]
+            # mlp branch: x2 = x1 + dp2 * (g @ W2^T + b2)
+            gi[10] = db2
+            gi[9] = _wgrad(d_o, g)
+            dg = d_o @ weight_cache.get(w2, adt)
+            df, gi[8] = bias_gelu_bwd(dg, f, b1, adt)
+            gi[7] = _wgrad(df, h2)
+            dh2 = df @ weight_cache.get(w1, adt)
+            dx1, d_p, s2 = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R)
+            gi[5], gi[6], gi[4] = s2[0], s2[1], s2[2]
+            # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
+            gi[3] = _wgrad(d_p, a)
+            da = d_p @ weight_cache.get(wproj, adt)
+            dqkv = _attention_bwd(qkv, a, da, lse, B, T, H, scale)
+            gi[2] = _wgrad(dqkv, h1)
+            dh1 = dqkv @ weight_cache.get(wqkv, adt)
+            G, d_o, s1 = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R)
+            gi[0], gi[1] = s1[0], s1[1]
+            db2 = s1[2]
+            grads[i * PER_BLOCK:(i + 1) * PER_BLOCK] = gi
+        dx = G.view(B, T, C).to(ctx.in_dtypes[0])
+        return (dx, dpos.view(B, T, C).to(ctx.in_dtypes[1]), None, g_final_w, g_final_b) + tuple(grads)
+
+
+def run_stack(blocks, final_norm, x, pos, training):
+    """blocks: iterable of Block modules; final_norm: nn.LayerNorm.  x, pos (B,T,384)."""
+    from . import models_mae_learn_loss as M  # drop_path_scale lives there (the tests replay recorded draws through it)
+    blocks = list(blocks)
+    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+        or x.dtype == torch.bfloat16 else torch.float32
+    B = x.shape[0]
+    dp = []
+    for b in blocks:
+        p = getattr(b.drop_path, "drop_prob", 0.0)
+        dp.append((M.drop_path_scale(B, p, training, x.device), M.drop_path_scale(B, p, training, x.device)))
+    meta = {"num_heads": blocks[0].attn.num_heads, "scale": blocks[0].attn.scale, "eps": blocks[0].norm1.eps,
+            "final_eps": final_norm.eps, "adt": adt, "dp": dp}
+    params = []
+    for b in blocks:
+        params += block_params(b)
+    return TransformerStackFn.apply(x, pos, meta, final_norm.weight, final_norm.bias, *params)

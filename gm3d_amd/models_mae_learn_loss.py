@@ -35,6 +35,18 @@ def drop_path(x, p, training):
     return x.div(keep) * m
 
 
+def drop_path_scale(B, p, training, device):
+    """Per-sample DropPath factor floor(keep + U[0,1)) / keep as an f32 (B,) vector, or None when inactive:
+    the form the fused transformer stack consumes (gm3d_amd/fused.py)."""
+    if p == 0.0 or not training:
+        return None
+    keep = 1.0 - p
+    return (keep + torch.rand(B, dtype=torch.float32, device=device)).floor_().div_(keep)
+
+
+FUSED_STACK = True   # False: per-op PyTorch modules below (kept as the in-package cross-check of the fused path)
+
+
 class DropPath(nn.Module):
     def __init__(self, drop_prob=0.0):
         super().__init__()
@@ -87,6 +99,16 @@ class Block(nn.Module):
         return x + self.drop_path(self.mlp(self.norm2(x)))
 
 
+def linear3(x, weight, bias):
+    """y = x @ weight^T + bias for in_features == 3 (xyz inputs), as three broadcast FMAs in fp32.
+    hipBLASLt is kept away from K=3 on purpose: a 3-element bf16 row is 6 bytes, no vector load is aligned,
+    and under hipGraph replay the K=3 GEMM path was observed to corrupt neighbouring small allocations."""
+    x = x.float()
+    w = weight.float()
+    y = x[..., 0:1] * w[:, 0] + x[..., 1:2] * w[:, 1] + x[..., 2:3] * w[:, 2]
+    return y + bias.float()
+
+
 class Encoder(nn.Module):
     """mini-PointNet token embed (P/:868-899).  Parameters keep the Conv1d/BatchNorm1d layout and names
     (encoder.first_conv.{0,1,3}, encoder.second_conv.{0,1,3}); the math runs on a (rows, channels)
@@ -105,7 +127,7 @@ class Encoder(nn.Module):
         c0, bn0, _, c1 = self.first_conv
         c2, bn1, _, c3 = self.second_conv
         x = point_groups.reshape(bs * g * n, 3)
-        h = F.relu(bn0(F.linear(x, c0.weight.squeeze(-1), c0.bias)))
+        h = F.relu(bn0(linear3(x, c0.weight.squeeze(-1), c0.bias)))
         f = F.linear(h, c1.weight.squeeze(-1), c1.bias)                      # (rows, 256)
         fg = f.view(bs * g, n, 256).amax(dim=1)                              # (groups, 256)
         w2 = c2.weight.squeeze(-1)                                           # [:, :256] global | [:, 256:] local
@@ -125,10 +147,15 @@ class TransformerEncoder(nn.Module):
                   drop_path=drop_path_rate[i] if isinstance(drop_path_rate, list) else drop_path_rate)
             for i in range(depth)])
 
-    def forward(self, x, pos):
+    def forward(self, x, pos, norm=None):
+        """`norm`: the LayerNorm the caller applies right after (norm_p, P/:303); passing it lets the whole
+        stack + norm run as one fused autograd node."""
+        if FUSED_STACK and norm is not None and x.is_cuda:
+            from . import fused
+            return fused.run_stack(self.blocks, norm, x, pos, self.training)
         for block in self.blocks:  # pos is re-added before EVERY block (P/:914-917)
             x = block(x + pos)
-        return x
+        return x if norm is None else norm(x)
 
 
 class TransformerDecoder(nn.Module):
@@ -154,6 +181,9 @@ class TransformerDecoder(nn.Module):
             nn.init.constant_(m.weight, 1.0)
 
     def forward(self, x, pos, return_token_num):
+        if FUSED_STACK and x.is_cuda:
+            from . import fused
+            return self.head(fused.run_stack(self.blocks, self.norm, x, pos, self.training))
         for block in self.blocks:
             x = block(x + pos)
         return self.head(self.norm(x))  # ALL tokens, like P/:989
@@ -240,15 +270,19 @@ class MaskedAutoencoderViT(nn.Module):
         self.loss_func = ChamferDistanceL2()
 
     # ------------------------------------------------------------------ forward pieces
+    def embed_pos(self, center):
+        """self.pos_embed (Linear(3,128) -> GELU -> Linear(128,384), P/:104-108) with the K=3 layer as FMAs."""
+        l0, act, l1 = self.pos_embed
+        return l1(act(linear3(center, l0.weight, l0.bias)))
+
     def _encode_visible(self, neighborhood, vis_ids, pos_all):
         tokens = self.encoder(neighborhood)  # B G C
-        x_vis = self.blocks(take(tokens, vis_ids), take(pos_all, vis_ids))
-        return self.norm_p(x_vis)
+        return self.blocks(take(tokens, vis_ids), take(pos_all, vis_ids), norm=self.norm_p)
 
     def forward_encoder_point(self, neighborhood, center, mask, num_visible=None):
         """P/:293-306: embed -> keep visible tokens -> pos -> 12 blocks -> norm_p."""
         vis_ids, _ = split_ids(mask, num_visible)
-        return self._encode_visible(neighborhood, vis_ids, self.pos_embed(center))
+        return self._encode_visible(neighborhood, vis_ids, self.embed_pos(center))
 
     def _loss_pred_head(self, x):
         """increase_dim_2 then mean over channels (P/:668,677): Conv1d(384,1024) -> BN1d -> LeakyReLU ->
@@ -267,7 +301,7 @@ class MaskedAutoencoderViT(nn.Module):
         teacher pass never reads, P/engine_pretrain.py:86-94)."""
         neighborhood, center, neighborhood_org = group if group is not None else self.group_divider(pts)
         vis_ids, mask_ids = split_ids(mask, num_visible)
-        pos_all = self.pos_embed(center)
+        pos_all = self.embed_pos(center)
         x_vis = self._encode_visible(neighborhood, vis_ids, pos_all)
         B, _, C = x_vis.shape
         if noaug:

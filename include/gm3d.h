@@ -107,6 +107,45 @@ int gm3d_attention_bwd(const void *qkv, const void *out, const void *dout, const
                        void *dqkv, int B, int T, int H, float scale, int dtype,
                        gm3d_stream_t stream);
 
+/* ---- Row-wise fused passes around the transformer-block GEMMs (gm3d_amd/csrc/rowops.hip) ------------
+ * Together they restate timm-0.4.5 Block.forward (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146)
+ * as driven by TransformerEncoder/Decoder.forward (models_mae_learn_loss.py:914-917,984-990).
+ * The residual stream is fp32; `dtype` (GM3D_F32 / GM3D_BF16) is the type of the GEMM-side tensors.
+ * C must be 384 (trans_dim) for the LayerNorm entry points. */
+
+/* out_res[r,:] = res[r,:] + rowscale[r / rows_per_sample] * (y[r,:] + bias) + add[r,:]
+ * h[r,:]       = LayerNorm(out_res[r,:]) * gamma + beta          (eps as given; mean/rstd saved per row)
+ * res/out_res f32 (R,C); y, add, h `dtype` (R,C); bias, gamma, beta f32 (C); rowscale f32 (R/rows_per_sample)
+ * = the DropPath keep/(1-p) factor per sample.  y, bias, rowscale, add, out_res, res may be NULL (at
+ * least one of res/y/add must be given). */
+int gm3d_residual_ln_fwd(const float *res, const void *y, const float *bias, const float *rowscale,
+                         int rows_per_sample, const void *add, const float *gamma, const float *beta,
+                         float eps, float *out_res, void *h, float *mean, float *rstd, int R, int C,
+                         int dtype, gm3d_stream_t stream);
+
+/* Backward of one such site.  dh (R,C) `dtype` = grad of h; gin (R,C) f32 = grad already flowing on the
+ * residual stream (NULL = none); x = the saved out_res.  Writes dx (R,C) f32 = grad wrt out_res,
+ * dy (R,C) `dtype` = rowscale * dx (NULL to skip), acc (R,C) f32 += dx (NULL to skip; positional grad),
+ * and per-workgroup column partial sums partial[gm3d_ln_partial_rows(R)][3][C] f32:
+ * [0] dgamma, [1] dbeta, [2] colsum(dy) (= gradient of `bias`). */
+int gm3d_residual_ln_bwd(const void *dh, const float *gin, const float *x, const float *mean,
+                         const float *rstd, const float *gamma, const float *rowscale, int rows_per_sample,
+                         float *dx, void *dy, float *acc, float *partial, int R, int C, int dtype,
+                         gm3d_stream_t stream);
+int gm3d_ln_partial_rows(int R);   /* rows of `partial` the call above writes */
+
+/* out[c] (+)= sum_{r<nrows} partial[r*pitch + c], c < ncols (second stage of the column sums). */
+int gm3d_colsum_finish(const float *partial, int nrows, int pitch, int ncols, float *out, int accumulate,
+                       gm3d_stream_t stream);
+
+/* g = GELU(f + bias), exact erf form (nn.GELU, Mlp at models/Point_MAE.py:82-98).  C % 8 == 0. */
+int gm3d_bias_gelu_fwd(const void *f, const float *bias, void *g, int R, int C, int dtype,
+                       gm3d_stream_t stream);
+/* df = dg * GELU'(f + bias); partial[gm3d_gelu_partial_rows(R)][C] f32 = column partial sums of df. */
+int gm3d_bias_gelu_bwd(const void *dg, const void *f, const float *bias, void *df, float *partial, int R,
+                       int C, int dtype, gm3d_stream_t stream);
+int gm3d_gelu_partial_rows(int R);
+
 #ifdef __cplusplus
 }
 #endif

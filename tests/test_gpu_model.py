@@ -37,7 +37,8 @@ def model(M):
 
 
 class FeedDropPath:
-    """Replays the reference run's DropPath keep-masks in call order."""
+    """Replays the reference run's DropPath keep-masks in call order, for both execution paths of the package:
+    `drop_path` (per-op modules) and `drop_path_scale` (fused stack)."""
 
     def __init__(self, masks):
         self.masks = [torch.from_numpy(m) for m in masks]
@@ -48,9 +49,18 @@ class FeedDropPath:
         m = self.masks.pop(0).to(x.device, x.dtype).reshape((x.shape[0],) + (1,) * (x.ndim - 1))
         return x.div(1.0 - p) * m
 
+    def scale(self, B, p, training, device):
+        if p == 0.0 or not training:
+            return None
+        return (self.masks.pop(0).to(device, torch.float32) / (1.0 - p)).contiguous()
 
+
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("case", ["b2_uniform", "b4_gaussian"])
-def test_against_reference_fixtures(M, model, case, monkeypatch):
+def test_against_reference_fixtures(M, model, case, fused, monkeypatch):
+    """fused=True: the hand-written transformer-stack forward/backward (gm3d_amd/fused.py, the default);
+    fused=False: the per-op PyTorch modules around the same HIP kernels."""
+    monkeypatch.setattr(M, "FUSED_STACK", fused)
     fx = np.load(os.path.join(GOLD, "pretrain_%s.npz" % case))
     saved = {k: v.clone() for k, v in model.state_dict().items()}
     try:
@@ -98,6 +108,7 @@ def _fixture_case(M, model, fx, monkeypatch):
     mask = torch.from_numpy(fx["mask_e200"]).bool().cuda()
     feed = FeedDropPath(fx["droppath_masks"])
     monkeypatch.setattr(M, "drop_path", feed)
+    monkeypatch.setattr(M, "drop_path_scale", feed.scale)
     s = model(samples, mask=mask)
     assert feed.masks == []
     Mn = int(fx["mask_num"])

@@ -1,0 +1,127 @@
+"""-m gpu: the row-wise fused kernels (gm3d_amd/csrc/rowops.hip) against plain PyTorch fp32/fp64 references of the
+same expressions (LayerNorm eps 1e-5, exact-erf GELU), forward and backward, fp32 (1e-5) and bf16 (bf16 rounding)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("adt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("R,T", [(25 * 8, 25), (64 * 37, 64), (3, 1), (5000, 1)])
+def test_residual_ln_fwd_bwd(adt, tol, R, T):
+    from gm3d_amd import fused
+    torch.manual_seed(R)
+    dev = "cuda"
+    res = torch.randn(R, 384, device=dev)
+    y = torch.randn(R, 384, device=dev).to(adt)
+    add = torch.randn(R, 384, device=dev).to(adt)
+    bias = torch.randn(384, device=dev) * 0.3
+    gamma = 1 + 0.2 * torch.randn(384, device=dev)
+    beta = 0.1 * torch.randn(384, device=dev)
+    rs = (torch.rand(R // T, device=dev) > 0.3).float() / 0.7
+    out_res, h, mean, rstd = fused.residual_ln_fwd(res, y, bias, rs, T, add, gamma, beta, 1e-5, adt, R)
+    rsr = rs.repeat_interleave(T).unsqueeze(1).double()
+    x64 = (res.double() + rsr * (y.double() + bias.double()) + add.double()).requires_grad_(True)
+    h64 = F.layer_norm(x64, (384,), gamma.double(), beta.double(), 1e-5)
+    assert rel(out_res, x64.detach()) <= 1e-6
+    assert rel(h, h64.detach()) <= tol
+    assert rel(mean, x64.detach().mean(1)) <= 1e-5 and rel(rstd, 1 / torch.sqrt(x64.detach().var(1, unbiased=False) + 1e-5)) <= 1e-5
+    # optional inputs absent
+    o2, h2, _, _ = fused.residual_ln_fwd(res, None, None, None, 1, None, gamma, beta, 1e-5, adt, R)
+    assert torch.equal(o2, res) and rel(h2, F.layer_norm(res.double(), (384,), gamma.double(), beta.double(), 1e-5)) <= tol
+
+    dh = torch.randn(R, 384, device=dev).to(adt)
+    gin = torch.randn(R, 384, device=dev)
+    acc = torch.ones(R, 384, device=dev)
+    dx, dy, sums = fused.residual_ln_bwd(dh, gin, out_res, mean, rstd, gamma, rs, T, acc, True, adt, R)
+    gam64 = gamma.double().requires_grad_(True)
+    bet64 = beta.double().requires_grad_(True)
+    x64b = out_res.double().requires_grad_(True)
+    hh = F.layer_norm(x64b, (384,), gam64, bet64, 1e-5)
+    hh.backward(dh.double())
+    dx_ref = x64b.grad + gin.double()
+    assert rel(dx, dx_ref) <= 2e-5
+    assert rel(acc, dx_ref + 1) <= 2e-5
+    assert rel(dy, rsr * dx_ref) <= tol
+    assert rel(sums[0], gam64.grad) <= 2e-5 and rel(sums[1], bet64.grad) <= 2e-5
+    assert rel(sums[2], (rsr * dx_ref).sum(0)) <= 2e-5      # summed in fp32 BEFORE dy is rounded to bf16
+
+
+@pytest.mark.parametrize("adt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 1.2e-2)])
+@pytest.mark.parametrize("R,C", [(200, 1536), (8192, 1536), (7, 128)])
+def test_bias_gelu_fwd_bwd(adt, tol, R, C):
+    from gm3d_amd import fused
+    torch.manual_seed(R + C)
+    f = (torch.randn(R, C, device="cuda") * 2).to(adt)
+    bias = torch.randn(C, device="cuda") * 0.5
+    dg = torch.randn(R, C, device="cuda").to(adt)
+    g = fused.bias_gelu_fwd(f, bias, adt)
+    pre = (f.double() + bias.double()).requires_grad_(True)
+    ref = F.gelu(pre)
+    assert rel(g, ref.detach()) <= tol
+    df, db = fused.bias_gelu_bwd(dg, f, bias, adt)
+    ref.backward(dg.double())
+    assert rel(df, pre.grad) <= tol
+    assert rel(db, pre.grad.sum(0)) <= 2e-5             # summed in fp32 BEFORE df is rounded to bf16
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("B,T,nblk,train", [(4, 25, 3, True), (3, 64, 2, False)])
+def test_fused_stack_matches_per_op_modules(bf16, B, T, nblk, train):
+    """Whole fused stack (forward + every gradient) vs the per-op PyTorch modules of the same package."""
+    from gm3d_amd import models_mae_learn_loss as M
+    torch.manual_seed(7)
+    dpr = [0.0, 0.2, 0.3][:nblk]
+    dec = M.TransformerDecoder(embed_dim=384, depth=nblk, drop_path_rate=dpr, num_heads=6).cuda().train(train)
+    for p in dec.parameters():
+        if p.dim() == 1:
+            p.data.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(B, T, 384, device="cuda")
+    pos = torch.randn(B, T, 384, device="cuda")
+    w = torch.randn(B, T, 384, device="cuda")
+    draws = {}
+
+    def scale(Bn, p, training, device):
+        if p == 0.0 or not training:
+            return None
+        k = len(draws.setdefault("s", []))
+        g = torch.Generator().manual_seed(100 + k)
+        m = ((1 - p) + torch.rand(Bn, generator=g)).floor_()
+        draws["s"].append(m)
+        return (m / (1 - p)).to(device)
+
+    def dpath(t, p, training):
+        if p == 0.0 or not training:
+            return t
+        k = len(draws.setdefault("d", []))
+        g = torch.Generator().manual_seed(100 + k)
+        m = ((1 - p) + torch.rand(t.shape[0], generator=g)).floor_().to(t.device, t.dtype)
+        draws["d"].append(m)
+        return t.div(1 - p) * m.reshape(-1, 1, 1)
+
+    res = {}
+    for fused_on in (False, True):
+        M.FUSED_STACK = fused_on
+        M.drop_path_scale, M.drop_path = scale, dpath
+        draws.clear()
+        xs, ps = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+        dec.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            out = dec(xs, ps, 0)
+        (out.float() * w).sum().backward()
+        res[fused_on] = (out.detach().float(), xs.grad.clone(), ps.grad.clone(),
+                         {k: p.grad.clone() for k, p in dec.named_parameters()})
+    M.FUSED_STACK = True
+    import importlib
+    importlib.reload(M)
+    tol = 3e-2 if bf16 else 2e-5
+    assert rel(res[True][0], res[False][0]) <= tol
+    assert rel(res[True][1], res[False][1]) <= tol and rel(res[True][2], res[False][2]) <= tol
+    for k in res[False][3]:
+        assert rel(res[True][3][k], res[False][3][k]) <= tol, k
