@@ -79,10 +79,11 @@ weight_cache = _WeightCache()
 
 
 # ----------------------------------------------------------------------------- row-op wrappers
-def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, eps, adt, R, want_res=True):
+def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, eps, adt, R, want_res=True, h=None):
     dev = gamma.device
     out_res = torch.empty(R, LNC, dtype=torch.float32, device=dev) if want_res else None
-    h = torch.empty(R, LNC, dtype=adt, device=dev)
+    if h is None:
+        h = torch.empty(R, LNC, dtype=adt, device=dev)
     mean = torch.empty(R, dtype=torch.float32, device=dev)
     rstd = torch.empty(R, dtype=torch.float32, device=dev)
     _launch("gm3d_residual_ln_fwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_fwd, _ptr(res), _ptr(y), _ptr(bias),
@@ -91,11 +92,12 @@ def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, e
     return out_res, h, mean, rstd
 
 
-def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R):
+def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R, dy=None):
     """-> dx (R,C) f32, dy (R,C) adt | None, sums (3,C) f32 = [dgamma, dbeta, colsum(dy)]."""
     dev = gamma.device
     dx = torch.empty(R, LNC, dtype=torch.float32, device=dev)
-    dy = torch.empty(R, LNC, dtype=adt, device=dev) if want_dy else None
+    if dy is None and want_dy:
+        dy = torch.empty(R, LNC, dtype=adt, device=dev)
     nrows = lib.gm3d_ln_partial_rows(R)
     partial = torch.empty(nrows, 3 * LNC, dtype=torch.float32, device=dev)
     _launch("gm3d_residual_ln_bwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_bwd, _ptr(dh), _ptr(gin), _ptr(x),
@@ -107,18 +109,20 @@ def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, ac
     return dx, dy, sums
 
 
-def bias_gelu_fwd(f, bias, adt):
+def bias_gelu_fwd(f, bias, adt, g=None):
     R, C = f.shape
-    g = torch.empty_like(f)
+    if g is None:
+        g = torch.empty_like(f)
     _launch("gm3d_bias_gelu_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_bias_gelu_fwd, _ptr(f), _ptr(bias), _ptr(g),
             R, C, _DT[adt], _stream())
     return g
 
 
-def bias_gelu_bwd(dg, f, bias, adt):
+def bias_gelu_bwd(dg, f, bias, adt, df=None):
     """-> df (R,C) adt, dbias (C) f32."""
     R, C = f.shape
-    df = torch.empty_like(f)
+    if df is None:
+        df = torch.empty_like(f)
     nrows = lib.gm3d_gelu_partial_rows(R)
     partial = torch.empty(nrows, C, dtype=torch.float32, device=f.device)
     _launch("gm3d_bias_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_bias_gelu_bwd, _ptr(dg), _ptr(f), _ptr(bias),
@@ -129,29 +133,33 @@ def bias_gelu_bwd(dg, f, bias, adt):
     return df, db
 
 
-def _attention_fwd(qkv, B, T, H, scale):
-    out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
+def _attention_fwd(qkv, B, T, H, scale, out=None):
+    if out is None:
+        out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
     _launch("gm3d_attention_fwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_fwd, _ptr(qkv),
             _ptr(out), _ptr(lse), B, T, H, float(scale), _DT[qkv.dtype], _stream())
     return out, lse
 
 
-def _attention_bwd(qkv, out, dout, lse, B, T, H, scale):
-    dqkv = torch.empty_like(qkv)
+def _attention_bwd(qkv, out, dout, lse, B, T, H, scale, dqkv=None):
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv)
     _launch("gm3d_attention_bwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_bwd, _ptr(qkv),
             _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, H, float(scale), _DT[qkv.dtype], _stream())
     return dqkv
 
 
-def _wgrad(dy, x):
-    """dW = dy^T @ x accumulated in fp32, returned fp32 (master-weight gradient)."""
+def _wgrad_batched(dy, x):
+    """dW[i] = dy[i]^T @ x[i] for every block of a stack in ONE batched GEMM, fp32 result.
+    (K = rows is 3200..8192 and the output is only 384..1536 wide: a single such GEMM fills a fraction of the
+    256 CUs -- 50 us each through hipBLASLt -- while the batch over blocks runs at ~16 us per block.)"""
     if dy.dtype == torch.float32:
-        return dy.t() @ x
+        return torch.bmm(dy.transpose(1, 2), x)
     try:
-        return torch.mm(dy.t(), x, out_dtype=torch.float32)
+        return torch.bmm(dy.transpose(1, 2), x, out_dtype=torch.float32)
     except TypeError:
-        return (dy.t() @ x).float()
+        return torch.bmm(dy.transpose(1, 2), x).float()
 
 
 PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
@@ -184,24 +192,30 @@ class TransformerStackFn(torch.autograd.Function):
         need = any(ctx.needs_input_grad)   # (forward runs with grad mode off; this is the reliable signal)
         y = bias = rs = None
         saved = []
+        dev = x.device
+        if need:  # operands of the weight-gradient GEMMs, stacked over blocks for the batched wgrad
+            H1 = torch.empty(nblk, R, C, dtype=adt, device=dev)
+            A = torch.empty(nblk, R, C, dtype=adt, device=dev)
+            H2 = torch.empty(nblk, R, C, dtype=adt, device=dev)
+            GG = torch.empty(nblk, R, 4 * C, dtype=adt, device=dev)
         for i in range(nblk):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             dp1, dp2 = meta["dp"][i]
-            u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R)
+            u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
             qkv = h1 @ weight_cache.get(wqkv, adt).t()
-            a, lse = _attention_fwd(qkv, B, T, H, scale)
+            a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
             p = a @ weight_cache.get(wproj, adt).t()
-            x1, h2, m2, r2 = residual_ln_fwd(u, p, bproj, dp1, T, None, ln2w, ln2b, eps, adt, R)
+            x1, h2, m2, r2 = residual_ln_fwd(u, p, bproj, dp1, T, None, ln2w, ln2b, eps, adt, R, h=H2[i] if need else None)
             f = h2 @ weight_cache.get(w1, adt).t()
-            g = bias_gelu_fwd(f, b1, adt)
+            g = bias_gelu_fwd(f, b1, adt, g=GG[i] if need else None)
             o = g @ weight_cache.get(w2, adt).t()
             if need:
-                saved += [u, h1, m1, r1, qkv, a, lse, x1, h2, m2, r2, f, g]
+                saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
             res, y, bias, rs = x1, o, b2, dp2
         xf, hout, mf, rf = residual_ln_fwd(res, y, bias, rs, T, None, final_w, final_b, meta["final_eps"], adt, R,
                                            want_res=need)
         if need:
-            ctx.save_for_backward(final_w, xf, mf, rf, *params, *saved)
+            ctx.save_for_backward(final_w, xf, mf, rf, H1, A, H2, GG, *params, *saved)
         ctx.meta, ctx.shape, ctx.nblk = meta, (B, T, C), nblk
         ctx.in_dtypes = (x.dtype, pos.dtype)
         return hout.view(B, T, C)
@@ -217,40 +231,49 @@ class TransformerStackFn(torch.autograd.Function):
         adt, H, scale = meta["adt"], meta["num_heads"], meta["scale"]
         R = B * T
         tens = ctx.saved_tensors
-        final_w, xf, mf, rf = tens[:4]
-        params = tens[4:4 + nblk * PER_BLOCK]
-        saved = tens[4 + nblk * PER_BLOCK:]
+        final_w, xf, mf, rf, H1, A, H2, GG = tens[:8]
+        params = tens[8:8 + nblk * PER_BLOCK]
+        saved = tens[8 + nblk * PER_BLOCK:]
         grads = [None] * (nblk * PER_BLOCK)
+        dev = dout.device
         dh = dout.reshape(R, C).to(adt).contiguous()
+        # output-side operands of the weight-gradient GEMMs, stacked over blocks
+        DO = torch.empty(nblk, R, C, dtype=adt, device=dev)
+        DF = torch.empty(nblk, R, 4 * C, dtype=adt, device=dev)
+        DP = torch.empty(nblk, R, C, dtype=adt, device=dev)
+        DQ = torch.empty(nblk, R, 3 * C, dtype=adt, device=dev)
         dp2_last = meta["dp"][nblk - 1][1]
-        G, d_o, sums = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R)
+        G, d_o, sums = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1])
         g_final_w, g_final_b, db2 = sums[0], sums[1], sums[2]
-        dpos = torch.zeros(R, C, dtype=torch.float32, device=dout.device)
+        dpos = torch.zeros(R, C, dtype=torch.float32, device=dev)
         for i in range(nblk - 1, -1, -1):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
-            u, h1, m1, r1, qkv, a, lse, x1, h2, m2, r2, f, g = saved[i * 13:(i + 1) * 13]
+            u, m1, r1, qkv, lse, x1, m2, r2, f = saved[i * 9:(i + 1) * 9]
             dp1 = meta["dp"][i][0]
             dp2_prev = meta["dp"][i - 1][1] if i > 0 else None
             gi = grads[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             # mlp branch: x2 = x1 + dp2 * (g @ W2^T + b2)
             gi[10] = db2
-            gi[9] = _wgrad(d_o, g)
             dg = d_o @ weight_cache.get(w2, adt)
-            df, gi[8] = bias_gelu_bwd(dg, f, b1, adt)
-            gi[7] = _wgrad(df, h2)
+            df, gi[8] = bias_gelu_bwd(dg, f, b1, adt, df=DF[i])
             dh2 = df @ weight_cache.get(w1, adt)
-            dx1, d_p, s2 = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R)
+            dx1, d_p, s2 = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R, dy=DP[i])
             gi[5], gi[6], gi[4] = s2[0], s2[1], s2[2]
             # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
-            gi[3] = _wgrad(d_p, a)
             da = d_p @ weight_cache.get(wproj, adt)
-            dqkv = _attention_bwd(qkv, a, da, lse, B, T, H, scale)
-            gi[2] = _wgrad(dqkv, h1)
+            dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
             dh1 = dqkv @ weight_cache.get(wqkv, adt)
-            G, d_o, s1 = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R)
+            G, d_o, s1 = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
+                                         dy=DO[i - 1] if i > 0 else None)
             gi[0], gi[1] = s1[0], s1[1]
             db2 = s1[2]
             grads[i * PER_BLOCK:(i + 1) * PER_BLOCK] = gi
+        # all weight gradients of the stack: 4 batched GEMMs
+        gw2, gw1 = _wgrad_batched(DO, GG), _wgrad_batched(DF, H2)
+        gwp, gwq = _wgrad_batched(DP, A), _wgrad_batched(DQ, H1)
+        for i in range(nblk):
+            grads[i * PER_BLOCK + 9], grads[i * PER_BLOCK + 7] = gw2[i], gw1[i]
+            grads[i * PER_BLOCK + 3], grads[i * PER_BLOCK + 2] = gwp[i], gwq[i]
         dx = G.view(B, T, C).to(ctx.in_dtypes[0])
         return (dx, dpos.view(B, T, C).to(ctx.in_dtypes[1]), None, g_final_w, g_final_b) + tuple(grads)
 
