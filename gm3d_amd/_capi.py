@@ -34,6 +34,19 @@ SIGNATURES = {
     "gm3d_bias_gelu_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_bias_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_gelu_partial_rows": [_i],
+    "gm3d_embed_partial_rows": [_i, _i, _i],
+    "gm3d_moments3": [_vp, _i, _vp, _vp],
+    "gm3d_pn_layer1_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_group_max_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gm3d_group_max_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gm3d_bn_bcast_stats": [_vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "gm3d_bn_bcast_apply_relu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gm3d_bn_bcast_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "gm3d_bn_bcast_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "gm3d_group_scatter_add": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
+    "gm3d_pn_layer1_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_colsum_finish_f64": [_vp, _i, _i, _i, _vp, _vp],
+    "gm3d_colsum_partial": [_vp, _i, _i, _vp, _i, _vp],
 }
 
 

@@ -22,6 +22,7 @@ SOURCES = {
     "chamfer.hip": ["-ffp-contract=off"],
     "attention.hip": [],
     "rowops.hip": [],
+    "embed.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,645 @@
+// Streaming kernels of the mini-PointNet token embed (forward and backward) for gfx950.
+//
+// Beneath: Encoder.forward, Point-MAE_SA3D/models_mae_learn_loss.py:868-899
+//   first_conv  = Conv1d(3,128) -> BatchNorm1d(128) -> ReLU -> Conv1d(128,256)
+//   global max over the k=32 points of a group, concat [global | local] (512)
+//   second_conv = Conv1d(512,512) -> BatchNorm1d(512) -> ReLU -> Conv1d(512,384);  max over k
+// on rows = B*G*k = 262,144 points per step (twice: EMA teacher in eval mode, student in train mode).
+//
+// The three wide 1x1 convolutions stay plain GEMMs (hipBLASLt); everything between them is here, each as ONE
+// pass over a (group, k, C) activation with 16-byte accesses:
+//   * layer 1 (K=3) + BatchNorm + ReLU are evaluated on the fly from xyz -- the (rows,128) pre-activation never
+//     exists, and its batch statistics are analytic in the 3x3 input moments (moments3_kernel);
+//   * concat([global, local]) @ W is local @ W_l + (global @ W_g)[group]: the per-group term `t` is broadcast
+//     inside the BatchNorm kernels instead of being materialised over the rows;
+//   * BatchNorm batch statistics, normalise+ReLU, both max-pools (with argmax for the backward scatter), the
+//     BatchNorm backward reductions/apply and the per-group gradient sums are single passes with per-workgroup
+//     partial column sums finished by gm3d_colsum_finish (deterministic, no atomics, and -- unlike PyTorch's
+//     multi-block reduce_kernel on this stack -- safe under hipGraph replay).
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 bf16_t;
+
+template <class T> struct V8;
+template <> struct V8<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+};
+template <> struct V8<bf16_t> {
+    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const v8 a = *reinterpret_cast<const v8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        v8 a;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+        *reinterpret_cast<v8*>(p) = a;
+    }
+};
+
+// Thread layout shared by the (G, K, C) kernels: a workgroup is SL row-slices x TPR threads per row, each
+// thread owning 8 consecutive channels (16 B in bf16).  C in {128, 256, 384, 512}; blockDim = SL * TPR.
+__device__ __forceinline__ int tpr_of(int C) { return C >> 3; }
+
+// ------------------------------------------------------------------ input moments (layer-1 BN statistics)
+// partial[block][0..2] = sum x_j, [3..8] = sum of xx, xy, xz, yy, yz, zz over this block's rows.
+__global__ __launch_bounds__(256) void moments3_kernel(const float* __restrict__ x, int R, double* __restrict__ partial) {
+    __shared__ double red[4][9];
+    double s[9];   // fp64: the layer-1 weight gradient cancels against these moments (see pn_layer1_bwd_stats_kernel)
+#pragma unroll
+    for (int i = 0; i < 9; ++i) s[i] = 0.0;
+    for (int r = blockIdx.x * 256 + threadIdx.x; r < R; r += gridDim.x * 256) {
+        const double a = x[(size_t)r * 3], b = x[(size_t)r * 3 + 1], c = x[(size_t)r * 3 + 2];
+        s[0] += a; s[1] += b; s[2] += c;
+        s[3] += a * a; s[4] += a * b; s[5] += a * c; s[6] += b * b; s[7] += b * c; s[8] += c * c;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        double v = s[i];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9) partial[(size_t)blockIdx.x * 9 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ------------------------------------------------------------------ layer 1: a1 = relu(x . wf^T + bf)
+// wf (C1,3), bf (C1): conv1 with the BatchNorm affine folded in.  One thread = 8 channels of one row.
+template <class T>
+__global__ __launch_bounds__(256) void pn_layer1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ wf,
+                                                            const float* __restrict__ bf, T* __restrict__ a1, int R, int C1) {
+    const int tpr = C1 >> 3;
+    const size_t total = (size_t)R * tpr;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t r = t / tpr;
+        const int c = (int)(t - r * tpr) * 8;
+        const float a = x[r * 3], b = x[r * 3 + 1], d = x[r * 3 + 2];
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float h = a * wf[(c + i) * 3] + b * wf[(c + i) * 3 + 1] + d * wf[(c + i) * 3 + 2] + bf[c + i];
+            v[i] = h > 0.f ? h : 0.f;
+        }
+        V8<T>::store(a1 + r * C1 + c, v);
+    }
+}
+
+// ------------------------------------------------------------------ max over the K rows of each group (+argmax)
+template <class T>
+__global__ void group_max_fwd_kernel(const T* __restrict__ in, const float* __restrict__ bias, T* __restrict__ out,
+                                     uint8_t* __restrict__ arg, int G, int K, int C) {
+    extern __shared__ float sm[];  // [SL][C] values, then [SL][C] argk (as float bits)
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float* sv = sm;
+    int* sa = reinterpret_cast<int*>(sm + SL * C);
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float best[8];
+        int bk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bk[i] = 0; }
+        for (int k = sl; k < K; k += SL) {
+            float v[8];
+            V8<T>::load(in + ((size_t)g * K + k) * C + c, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                if (v[i] > best[i]) { best[i] = v[i]; bk[i] = k; }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { sv[sl * C + c + i] = best[i]; sa[sl * C + c + i] = bk[i]; }
+        __syncthreads();
+        if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float b = sv[c + i];
+                int kk = sa[c + i];
+                for (int s2 = 1; s2 < SL; ++s2) {
+                    const float v = sv[s2 * C + c + i];
+                    const int k2 = sa[s2 * C + c + i];
+                    if (v > b || (v == b && k2 < kk)) { b = v; kk = k2; }   // first maximum wins
+                }
+                best[i] = bias ? b + bias[c + i] : b;
+                arg[(size_t)g * C + c + i] = (uint8_t)kk;
+            }
+            V8<T>::store(out + (size_t)g * C + c, best);
+        }
+        __syncthreads();
+    }
+}
+
+// din[g,k,c] = (k == arg[g,c]) ? dout[g,c] : 0      (dense scatter: the GEMMs that follow want a dense operand)
+template <class T>
+__global__ void group_max_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg, T* __restrict__ din,
+                                     int G, int K, int C) {
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float d[8];
+        V8<T>::load(dout + (size_t)g * C + c, d);
+        int a[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = arg[(size_t)g * C + c + i];
+        for (int k = sl; k < K; k += SL) {
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = a[i] == k ? d[i] : 0.f;
+            V8<T>::store(din + ((size_t)g * K + k) * C + c, v);
+        }
+    }
+}
+
+// Per-workgroup column partials: every thread accumulates its 8 channels over the rows it visits; the SL
+// slices of a workgroup meet in LDS once, at the end.  NQ quantities per channel.
+template <int NQ>
+__device__ __forceinline__ void write_partials(float (&acc)[NQ][8], float* sm, float* partial, int C, int c, int sl, int SL) {
+    // sm: [SL][NQ*C]
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm[(size_t)sl * NQ * C + q * C + c + i] = acc[q][i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < NQ * C; t += blockDim.x) {
+        float s = 0.f;
+        for (int s2 = 0; s2 < SL; ++s2) s += sm[(size_t)s2 * NQ * C + t];
+        partial[(size_t)blockIdx.x * NQ * C + t] = s;
+    }
+}
+
+// y = y0 + t[group]:  partial[block][0][c] = sum y, [1][c] = sum y^2
+template <class T>
+__global__ void bn_bcast_stats_kernel(const T* __restrict__ y0, const T* __restrict__ t, int G, int K, int C,
+                                      float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[0][i] = acc[1][i] = 0.f;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float tv[8];
+        V8<T>::load(t + (size_t)g * C + c, tv);
+        for (int k = sl; k < K; k += SL) {
+            float v[8];
+            V8<T>::load(y0 + ((size_t)g * K + k) * C + c, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float y = v[i] + tv[i]; acc[0][i] += y; acc[1][i] += y * y; }
+        }
+    }
+    write_partials<2>(acc, sm, partial, C, c, sl, SL);
+}
+
+// a2 = relu((y0 + t[group]) * scale + shift)
+template <class T>
+__global__ void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __restrict__ t, const float* __restrict__ scale,
+                                           const float* __restrict__ shift, T* __restrict__ a2, int G, int K, int C) {
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float tv[8];
+        V8<T>::load(t + (size_t)g * C + c, tv);
+        for (int k = sl; k < K; k += SL) {
+            float v[8];
+            const size_t o = ((size_t)g * K + k) * C + c;
+            V8<T>::load(y0 + o, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float h = (v[i] + tv[i]) * sc[i] + sh[i]; v[i] = h > 0.f ? h : 0.f; }
+            V8<T>::store(a2 + o, v);
+        }
+    }
+}
+
+// BatchNorm(+ReLU) backward, pass 1: g = da2 * [scale*y+shift > 0], yhat = (y - mean) * rstd
+//   partial[block][0][c] = sum g, [1][c] = sum g * yhat
+template <class T>
+__global__ void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
+                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd, int G, int K, int C,
+                                          float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float sc[8], sh[8], mu[8], rs[8], acc[2][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; acc[0][i] = acc[1][i] = 0.f; }
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float tv[8];
+        V8<T>::load(t + (size_t)g * C + c, tv);
+        for (int k = sl; k < K; k += SL) {
+            float v[8], d[8];
+            const size_t o = ((size_t)g * K + k) * C + c;
+            V8<T>::load(y0 + o, v);
+            V8<T>::load(da2 + o, d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = v[i] + tv[i];
+                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : 0.f;
+                acc[0][i] += gg; acc[1][i] += gg * (y - mu[i]) * rs[i];
+            }
+        }
+    }
+    write_partials<2>(acc, sm, partial, C, c, sl, SL);
+}
+
+// pass 2: dy = scale * (g - s1/R - yhat * s2/R)   (scale = gamma*rstd)      -> T (G,K,C)
+//         dt[g,c] = sum_k dy[g,k,c]                                           -> f32 (G,C)   (grad of the broadcast term)
+template <class T>
+__global__ void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
+                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                          const float* __restrict__ s1, const float* __restrict__ s2, float inv_rows,
+                                          T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C) {
+    extern __shared__ float sm[];  // [SL][C]
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float sc[8], sh[8], mu[8], rs[8], m1[8], m2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i];
+        m1[i] = s1[c + i] * inv_rows; m2[i] = s2[c + i] * inv_rows;
+    }
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float tv[8], gs[8];
+        V8<T>::load(t + (size_t)g * C + c, tv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gs[i] = 0.f;
+        for (int k = sl; k < K; k += SL) {
+            float v[8], d[8];
+            const size_t o = ((size_t)g * K + k) * C + c;
+            V8<T>::load(y0 + o, v);
+            V8<T>::load(da2 + o, d);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float y = v[i] + tv[i];
+                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : 0.f;
+                const float r = sc[i] * (gg - m1[i] - (y - mu[i]) * rs[i] * m2[i]);
+                v[i] = r; gs[i] += r;
+            }
+            V8<T>::store(dy + o, v);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sm[sl * C + c + i] = gs[i];
+        __syncthreads();
+        if (sl == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float s = 0.f;
+                for (int q = 0; q < SL; ++q) s += sm[q * C + c + i];
+                dt[(size_t)g * C + c + i] = s;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// df[g, arg[g,c], c] += dfg[g,c] (the max-pool branch of the first stage), in place; partial[block][c] = column
+// sums of the resulting df (gradient of the conv bias in front of it).
+template <class T>
+__global__ void group_scatter_add_kernel(T* __restrict__ df, const T* __restrict__ dfg, const uint8_t* __restrict__ arg,
+                                         int G, int K, int C, float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float acc[1][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        float d[8];
+        int a[8];
+        V8<T>::load(dfg + (size_t)g * C + c, d);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = arg[(size_t)g * C + c + i];
+        for (int k = sl; k < K; k += SL) {
+            float v[8];
+            const size_t o = ((size_t)g * K + k) * C + c;
+            V8<T>::load(df + o, v);
+            bool hit = false;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (a[i] == k) { v[i] += d[i]; hit = true; }
+                acc[0][i] += v[i];
+            }
+            if (hit) V8<T>::store(df + o, v);
+        }
+    }
+    write_partials<1>(acc, sm, partial, C, c, sl, SL);
+}
+
+// Layer-1 backward reductions (conv K=3 + BatchNorm + ReLU), nothing of size (rows,128) is written:
+//   g1 = da1 * [a1 > 0],  hhat = (x.w1 + b1 - mean) * rstd,  xc = x - xmean
+//   partial[block][q][c]: q=0 sum g1, q=1 sum g1*hhat, q=2..4 sum g1*xc_j
+// The weight gradient is the small difference of these large sums, so they are accumulated and finished in
+// fp64 (full-rate on CDNA vector units; this kernel is bandwidth-bound anyway).
+template <class T>
+__global__ void pn_layer1_bwd_stats_kernel(const T* __restrict__ da1, const T* __restrict__ a1, const float* __restrict__ x,
+                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                           const float* __restrict__ xmean, int R, int C1, double* __restrict__ partial) {
+    extern __shared__ double smd[];
+    const int tpr = C1 >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float wx[8], wy[8], wz[8], bb[8], rs[8];
+    double acc[5][8];
+    const float mx = xmean[0], my = xmean[1], mz = xmean[2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wx[i] = w1[(c + i) * 3]; wy[i] = w1[(c + i) * 3 + 1]; wz[i] = w1[(c + i) * 3 + 2];
+        bb[i] = b1[c + i] - mean[c + i]; rs[i] = rstd[c + i];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) acc[q][i] = 0.0;
+    }
+    for (size_t r = (size_t)blockIdx.x * SL + sl; r < (size_t)R; r += (size_t)gridDim.x * SL) {
+        float d[8], a[8];
+        V8<T>::load(da1 + r * C1 + c, d);
+        V8<T>::load(a1 + r * C1 + c, a);
+        const float px = x[r * 3], py = x[r * 3 + 1], pz = x[r * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float gg = a[i] > 0.f ? d[i] : 0.f;
+            const float hh = (px * wx[i] + py * wy[i] + pz * wz[i] + bb[i]) * rs[i];
+            acc[0][i] += (double)gg; acc[1][i] += (double)gg * (double)hh;
+            acc[2][i] += (double)gg * (double)(px - mx); acc[3][i] += (double)gg * (double)(py - my);
+            acc[4][i] += (double)gg * (double)(pz - mz);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) smd[(size_t)sl * 5 * C1 + q * C1 + c + i] = acc[q][i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 5 * C1; t += blockDim.x) {
+        double s = 0.0;
+        for (int s2 = 0; s2 < SL; ++s2) s += smd[(size_t)s2 * 5 * C1 + t];
+        partial[(size_t)blockIdx.x * 5 * C1 + t] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __restrict__ partial, int nrows, int pitch,
+                                                                int ncols, double* __restrict__ out) {
+    __shared__ double red[8][32];
+    const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    double s = 0.0;
+    if (c < ncols)
+        for (int r = slice; r < nrows; r += 8) s += partial[(size_t)r * pitch + c];
+    red[slice][cx] = s;
+    __syncthreads();
+    if (slice == 0 && c < ncols) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t += red[k][cx];
+        out[c] = t;
+    }
+}
+
+// Generic column partial sums of a (R,C) matrix: partial[block][c]
+template <class T>
+__global__ void colsum_partial_kernel(const T* __restrict__ m, int R, int C, float* __restrict__ partial) {
+    extern __shared__ float sm[];
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float acc[1][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) acc[0][i] = 0.f;
+    for (size_t r = (size_t)blockIdx.x * SL + sl; r < (size_t)R; r += (size_t)gridDim.x * SL) {
+        float v[8];
+        V8<T>::load(m + r * C + c, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[0][i] += v[i];
+    }
+    write_partials<1>(acc, sm, partial, C, c, sl, SL);
+}
+
+static inline bool chan_ok(int C) { return C >= 8 && C % 8 == 0 && C <= 1024; }
+static inline int threads_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; if (sl < 1) sl = 1; return sl * tpr; }
+static inline int slices_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; return sl < 1 ? 1 : sl; }
+static inline int group_grid(int G) { return G < 1024 ? G : 1024; }
+static inline int row_grid(int R, int C) { const int sl = slices_for(C); int g = (R + sl - 1) / sl; return g < 1 ? 1 : (g > 1024 ? 1024 : g); }
+static inline int moments_grid(int R) { int g = (R + 255) / 256; return g < 1 ? 1 : (g > 256 ? 256 : g); }
+
+}  // namespace gm3d
+
+#define GM3D_DISPATCH(dtype, CALL_BF16, CALL_F32) \
+    do { if ((dtype) == GM3D_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int gm3d_embed_partial_rows(int kind, int n, int C) {
+    using namespace gm3d;
+    if (kind == 0) return moments_grid(n);        // moments3: n = rows
+    if (kind == 1) return group_grid(n);          // (G,K,C) kernels: n = groups
+    if (kind == 3) { int g = (n + 7) / 8; return g > 1024 ? 1024 : (g < 1 ? 1 : g); }   // gm3d_pn_layer1_bwd_stats
+    return row_grid(n, C);                        // (R,C) kernels: n = rows
+}
+
+extern "C" int gm3d_moments3(const float* x, int R, double* partial, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!x || !partial || R < 1) return GM3D_EINVAL;
+    hipLaunchKernelGGL(moments3_kernel, dim3(moments_grid(R)), dim3(256), 0, (hipStream_t)stream, x, R, partial);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_pn_layer1_fwd(const float* x, const float* wf, const float* bf, void* a1, int R, int C1, int dtype,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!x || !wf || !bf || !a1 || R < 1) return GM3D_EINVAL;
+    if (!chan_ok(C1)) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const size_t total = (size_t)R * (C1 / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(pn_layer1_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, wf, bf, (bf16_t*)a1, R, C1),
+                  hipLaunchKernelGGL(pn_layer1_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, x, wf, bf, (float*)a1, R, C1));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+static int gkc_check(const void* a, const void* b, int G, int K, int C, int dtype) {
+    if (!a || !b || G < 1 || K < 1) return GM3D_EINVAL;
+    if (!gm3d::chan_ok(C) || K > 255) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_group_max_fwd(const void* in, const float* bias, void* out, uint8_t* arg, int G, int K, int C, int dtype,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(in, out, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!arg) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * C * 8;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(group_max_fwd_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const bf16_t*)in, bias, (bf16_t*)out, arg, G, K, C),
+                  hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const float*)in, bias, (float*)out, arg, G, K, C));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_group_max_bwd(const void* dout, const uint8_t* arg, void* din, int G, int K, int C, int dtype,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(dout, din, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!arg) return GM3D_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(group_max_bwd_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
+                                     (const bf16_t*)dout, arg, (bf16_t*)din, G, K, C),
+                  hipLaunchKernelGGL(group_max_bwd_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
+                                     (const float*)dout, arg, (float*)din, G, K, C));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_bcast_stats(const void* y0, const void* t, int G, int K, int C, float* partial, int dtype,
+                                   gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(y0, t, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!partial) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * 2 * C * 4;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(bn_bcast_stats_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const bf16_t*)y0, (const bf16_t*)t, G, K, C, partial),
+                  hipLaunchKernelGGL(bn_bcast_stats_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const float*)y0, (const float*)t, G, K, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const float* scale, const float* shift, void* a2,
+                                        int G, int K, int C, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(y0, t, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!scale || !shift || !a2) return GM3D_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
+                                     (const bf16_t*)y0, (const bf16_t*)t, scale, shift, (bf16_t*)a2, G, K, C),
+                  hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
+                                     (const float*)y0, (const float*)t, scale, shift, (float*)a2, G, K, C));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const void* t, const float* scale,
+                                       const float* shift, const float* mean, const float* rstd, int G, int K, int C,
+                                       float* partial, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(y0, t, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!da2 || !scale || !shift || !mean || !rstd || !partial) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * 2 * C * 4;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, G, K, C, partial),
+                  hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, G, K, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const void* t, const float* scale,
+                                       const float* shift, const float* mean, const float* rstd, const float* s1,
+                                       const float* s2, void* dy, float* dt, int G, int K, int C, int dtype,
+                                       gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(y0, t, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!da2 || !scale || !shift || !mean || !rstd || !s1 || !s2 || !dy || !dt) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * C * 4;
+    const float inv_rows = 1.0f / ((float)G * (float)K);
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, s1, s2,
+                                     inv_rows, (bf16_t*)dy, dt, G, K, C),
+                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, s1, s2,
+                                     inv_rows, (float*)dy, dt, G, K, C));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_group_scatter_add(void* df, const void* dfg, const uint8_t* arg, int G, int K, int C, float* partial,
+                                      int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    int rc = gkc_check(df, dfg, G, K, C, dtype);
+    if (rc != GM3D_OK) return rc;
+    if (!arg || !partial) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * C * 4;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(group_scatter_add_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (bf16_t*)df, (const bf16_t*)dfg, arg, G, K, C, partial),
+                  hipLaunchKernelGGL(group_scatter_add_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                                     (float*)df, (const float*)dfg, arg, G, K, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_pn_layer1_bwd_stats(const void* da1, const void* a1, const float* x, const float* w1, const float* b1,
+                                        const float* mean, const float* rstd, const float* xmean, int R, int C1,
+                                        double* partial, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!da1 || !a1 || !x || !w1 || !b1 || !mean || !rstd || !xmean || !partial || R < 1) return GM3D_EINVAL;
+    if (!chan_ok(C1) || C1 > 256) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const int tpr = C1 / 8, sl = 8;                       // 8 slices: fp64 LDS tile stays under 64 KB
+    const size_t lds = (size_t)sl * 5 * C1 * sizeof(double);
+    int grid = (R + sl - 1) / sl; grid = grid > 1024 ? 1024 : grid;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(pn_layer1_bwd_stats_kernel<bf16_t>, dim3(grid), dim3(sl * tpr), lds, st,
+                                     (const bf16_t*)da1, (const bf16_t*)a1, x, w1, b1, mean, rstd, xmean, R, C1, partial),
+                  hipLaunchKernelGGL(pn_layer1_bwd_stats_kernel<float>, dim3(grid), dim3(sl * tpr), lds, st,
+                                     (const float*)da1, (const float*)a1, x, w1, b1, mean, rstd, xmean, R, C1, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_colsum_finish_f64(const double* partial, int nrows, int pitch, int ncols, double* out,
+                                      gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!partial || !out || nrows < 0 || ncols < 1 || pitch < ncols) return GM3D_EINVAL;
+    hipLaunchKernelGGL(colsum_finish_f64_kernel, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows,
+                       pitch, ncols, out);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_colsum_partial(const void* m, int R, int C, float* partial, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!m || !partial || R < 1) return GM3D_EINVAL;
+    if (!chan_ok(C)) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const size_t lds = (size_t)slices_for(C) * C * 4;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(row_grid(R, C)), dim3(threads_for(C)), lds, st,
+                                     (const bf16_t*)m, R, C, partial),
+                  hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(row_grid(R, C)), dim3(threads_for(C)), lds, st,
+                                     (const float*)m, R, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

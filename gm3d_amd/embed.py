@@ -1,0 +1,256 @@
+"""Mini-PointNet token embed (Encoder.forward, Point-MAE_SA3D/models_mae_learn_loss.py:868-899) as ONE autograd
+node: three wide GEMMs (hipBLASLt) with every pass between them a hand-written streaming kernel
+(gm3d_amd/csrc/embed.hip), forward and backward.
+
+    x (rows,3) --[K=3 conv + BN1 + ReLU on the fly]--> a1 (rows,128) --GEMM--> f (rows,256)
+      fg = max_k f ; t = fg @ W3[:, :256]^T + b3 (per group) ; y0 = f @ W3[:, 256:]^T
+      a2 = ReLU(BN2(y0 + t[group])) --GEMM--> z (rows,384) ; tokens = max_k z + b4
+
+Identities used (exact up to fp32 rounding order): concat([global,local]) @ W = local @ W_l + global @ W_g;
+max_k(z) + b = max_k(z + b); the batch statistics of the K=3 layer follow from the 3x3 input moments; a bias in
+front of a BatchNorm has zero gradient.  Train mode updates the BatchNorm running statistics exactly like
+nn.BatchNorm1d (momentum 0.1, unbiased running variance, num_batches_tracked += 1).
+"""
+import torch
+
+from ._capi import lib
+from .fused import weight_cache, LNC  # noqa: F401
+from .ops import _launch, _ptr, _stream, _DT
+
+SPLITK = 64  # row chunks of the weight-gradient GEMMs (K = 262,144 rows would otherwise run on a handful of CUs)
+
+
+def _finish(partial, nrows, ncols, pitch=None):
+    out = torch.empty(ncols, dtype=torch.float32, device=partial.device)
+    _launch("gm3d_colsum_finish", {"rows": nrows, "cols": ncols}, lib.gm3d_colsum_finish, _ptr(partial), nrows,
+            pitch or ncols, ncols, _ptr(out), 0, _stream())
+    return out
+
+
+def colsum(m, adt):
+    """column sums of a contiguous (R,C) matrix -> (C,) f32 (two deterministic stages)."""
+    R, C = m.shape
+    nrows = lib.gm3d_embed_partial_rows(2, R, C)
+    partial = torch.empty(nrows, C, dtype=torch.float32, device=m.device)
+    _launch("gm3d_colsum_partial", {"R": R, "C": C, "dtype": str(m.dtype)}, lib.gm3d_colsum_partial, _ptr(m), R, C,
+            _ptr(partial), _DT[m.dtype], _stream())
+    return _finish(partial, nrows, C)
+
+
+def splitk_wgrad(dy, x):
+    """dW (N,K) f32 = dy (R,N)^T @ x (R,K) with R split into SPLITK batched chunks + a deterministic sum."""
+    R, N = dy.shape
+    K = x.shape[1]
+    S = SPLITK if R % SPLITK == 0 and R >= 64 * SPLITK else 1
+    a = dy.view(S, R // S, N).transpose(1, 2)
+    b = x.view(S, R // S, K)
+    if dy.dtype == torch.float32:
+        part = torch.bmm(a, b)
+    else:
+        try:
+            part = torch.bmm(a, b, out_dtype=torch.float32)
+        except TypeError:
+            part = torch.bmm(a, b).float()
+    if S == 1:
+        return part[0]
+    return _finish(part.view(S, N * K), S, N * K).view(N, K)
+
+
+def _gkc(name, fn, meta, *args):
+    _launch(name, meta, fn, *args)
+
+
+class EmbedFn(torch.autograd.Function):
+    """args: nb (B,G,K,3) f32, meta, w1,b1,g1,be1, w2,b2, w3,b3,g2,be2, w4,b4, then the BatchNorm buffers
+    rm1,rv1,nbt1, rm2,rv2,nbt2 (updated in place in train mode).  Returns tokens (B,G,C4) in meta['adt']."""
+
+    @staticmethod
+    def forward(ctx, nb, meta, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, rm1, rv1, nbt1, rm2, rv2, nbt2):
+        with torch.autocast("cuda", enabled=False):
+            return EmbedFn._forward(ctx, nb, meta, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, rm1, rv1, nbt1,
+                                    rm2, rv2, nbt2)
+
+    @staticmethod
+    def _forward(ctx, nb, meta, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, rm1, rv1, nbt1, rm2, rv2, nbt2):
+        adt, training, eps, mom = meta["adt"], meta["training"], meta["eps"], meta["momentum"]
+        dt_id = _DT[adt]
+        B, G, K, _ = nb.shape
+        BG, R = B * G, B * G * K
+        dev = nb.device
+        x = nb.reshape(R, 3).float().contiguous()
+        C1, C2, C3, C4 = w1.shape[0], w2.shape[0], w3.shape[0], w4.shape[0]
+        W1 = w1.reshape(C1, 3)
+        f64 = torch.float64
+        # ---- layer 1 statistics (analytic in the input moments) ----
+        if training:
+            nrows = lib.gm3d_embed_partial_rows(0, R, 0)
+            part = torch.empty(nrows, 9, dtype=f64, device=dev)
+            _launch("gm3d_moments3", {"R": R}, lib.gm3d_moments3, _ptr(x), R, _ptr(part), _stream())
+            mom9 = torch.empty(9, dtype=f64, device=dev)
+            _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": 9}, lib.gm3d_colsum_finish_f64, _ptr(part), nrows, 9, 9,
+                    _ptr(mom9), _stream())
+            mom9 = mom9 / R
+            m = mom9[:3]
+            S = torch.stack([mom9[[3, 4, 5]], mom9[[4, 6, 7]], mom9[[5, 7, 8]]])
+            cov = S - torch.outer(m, m)
+            W64 = W1.detach().to(f64)
+            mean1 = W64 @ m + b1.detach().to(f64)
+            var1 = ((W64 @ cov) * W64).sum(1).clamp_min(0.0)
+            with torch.no_grad():
+                rm1.mul_(1 - mom).add_(mean1.to(rm1.dtype), alpha=mom)
+                rv1.mul_(1 - mom).add_((var1 * (R / (R - 1.0))).to(rv1.dtype), alpha=mom)
+                nbt1.add_(1)
+        else:
+            m = S = None
+            mean1, var1 = rm1.to(f64), rv1.to(f64)
+        rstd1 = torch.rsqrt(var1 + eps)
+        scale1 = g1.detach().to(f64) * rstd1
+        wf = (W1.detach().to(f64) * scale1[:, None]).float().contiguous()
+        bf = ((b1.detach().to(f64) - mean1) * scale1 + be1.detach().to(f64)).float().contiguous()
+        a1 = torch.empty(R, C1, dtype=adt, device=dev)
+        _launch("gm3d_pn_layer1_fwd", {"R": R, "C": C1, "dtype": str(adt)}, lib.gm3d_pn_layer1_fwd, _ptr(x), _ptr(wf),
+                _ptr(bf), _ptr(a1), R, C1, dt_id, _stream())
+        # ---- conv2 + max-pool ----
+        W2 = weight_cache.get(w2, adt).reshape(C2, C1)
+        f = torch.addmm(b2.detach().to(adt), a1, W2.t())
+        fg = torch.empty(BG, C2, dtype=adt, device=dev)
+        arg1 = torch.empty(BG, C2, dtype=torch.uint8, device=dev)
+        _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(f), None,
+                _ptr(fg), _ptr(arg1), BG, K, C2, dt_id, _stream())
+        # ---- conv3 on [global | local] ----
+        W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
+        W3g, W3l = W3[:, :C2], W3[:, C2:]
+        t = torch.addmm(b3.detach().to(adt), fg, W3g.t())
+        y0 = f @ W3l.t()
+        if training:
+            nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
+            part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
+            _launch("gm3d_bn_bcast_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
+                    _ptr(t), BG, K, C3, _ptr(part), dt_id, _stream())
+            st = _finish(part, nrows, 2 * C3).to(f64) / R
+            mean2 = st[:C3]
+            var2 = (st[C3:] - mean2 * mean2).clamp_min(0.0)
+            with torch.no_grad():
+                rm2.mul_(1 - mom).add_(mean2.to(rm2.dtype), alpha=mom)
+                rv2.mul_(1 - mom).add_((var2 * (R / (R - 1.0))).to(rv2.dtype), alpha=mom)
+                nbt2.add_(1)
+        else:
+            mean2, var2 = rm2.to(f64), rv2.to(f64)
+        rstd2 = torch.rsqrt(var2 + eps)
+        scale2 = (g2.detach().to(f64) * rstd2).float()
+        shift2 = (be2.detach().to(f64) - mean2 * g2.detach().to(f64) * rstd2).float()
+        a2 = torch.empty(R, C3, dtype=adt, device=dev)
+        _launch("gm3d_bn_bcast_apply_relu", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
+                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, dt_id, _stream())
+        # ---- conv4 + max-pool ----
+        W4 = weight_cache.get(w4, adt).reshape(C4, C3)
+        z = a2 @ W4.t()
+        tok = torch.empty(BG, C4, dtype=adt, device=dev)
+        arg2 = torch.empty(BG, C4, dtype=torch.uint8, device=dev)
+        b4f = b4.detach().float().contiguous()
+        _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
+                _ptr(b4f), _ptr(tok), _ptr(arg2), BG, K, C4, dt_id, _stream())
+        if meta["grad"] and any(ctx.needs_input_grad):
+            if not training:
+                raise NotImplementedError("EmbedFn backward is implemented for train-mode BatchNorm only")
+            ctx.save_for_backward(x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, m, S,
+                                  mean1.float(), rstd1.float(), mean2.float(), rstd2.float(), scale2, shift2)
+            ctx.meta, ctx.dims = meta, (B, G, K, C1, C2, C3, C4)
+        return tok.view(B, G, C4)
+
+    @staticmethod
+    def backward(ctx, dtok):
+        with torch.autocast("cuda", enabled=False):
+            return EmbedFn._backward(ctx, dtok)
+
+    @staticmethod
+    def _backward(ctx, dtok):
+        (x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, m, S, mean1, rstd1, mean2, rstd2, scale2,
+         shift2) = ctx.saved_tensors
+        adt = ctx.meta["adt"]
+        dt_id = _DT[adt]
+        B, G, K, C1, C2, C3, C4 = ctx.dims
+        BG, R = B * G, B * G * K
+        dev = dtok.device
+        f64 = torch.float64
+        dtok = dtok.reshape(BG, C4).to(adt).contiguous()
+        db4 = colsum(dtok, adt)
+        # conv4
+        dz = torch.empty(R, C4, dtype=adt, device=dev)
+        _launch("gm3d_group_max_bwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_bwd, _ptr(dtok),
+                _ptr(arg2), _ptr(dz), BG, K, C4, dt_id, _stream())
+        W4 = weight_cache.get(w4, adt).reshape(C4, C3)
+        da2 = dz @ W4
+        dW4 = splitk_wgrad(dz, a2)
+        # BN2 + ReLU
+        nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
+        part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
+        _launch("gm3d_bn_bcast_bwd_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats,
+                _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), BG, K, C3, _ptr(part),
+                dt_id, _stream())
+        s12 = _finish(part, nrows, 2 * C3)
+        s1, s2 = s12[:C3], s12[C3:]
+        dy = torch.empty(R, C3, dtype=adt, device=dev)
+        dt = torch.empty(BG, C3, dtype=torch.float32, device=dev)
+        _launch("gm3d_bn_bcast_bwd_apply", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply,
+                _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), _ptr(s1), _ptr(s2),
+                _ptr(dy), _ptr(dt), BG, K, C3, dt_id, _stream())
+        dg2, dbe2 = s2, s1
+        # conv3: local part on rows, global part per group
+        W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
+        W3g, W3l = W3[:, :C2], W3[:, C2:]
+        df = dy @ W3l
+        dW3l = splitk_wgrad(dy, f)
+        db3 = colsum(dt, torch.float32)
+        dta = dt.to(adt)
+        dW3g = splitk_wgrad(dta, fg)
+        dfg = dta @ W3g
+        dW3 = torch.cat([dW3g, dW3l], dim=1).reshape(w3.shape)
+        # max-pool branch joins df; bias grad of conv2
+        nrows = lib.gm3d_embed_partial_rows(1, BG, C2)
+        part = torch.empty(nrows, C2, dtype=torch.float32, device=dev)
+        _launch("gm3d_group_scatter_add", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_scatter_add, _ptr(df),
+                _ptr(dfg), _ptr(arg1), BG, K, C2, _ptr(part), dt_id, _stream())
+        db2 = _finish(part, nrows, C2)
+        # conv2
+        W2 = weight_cache.get(w2, adt).reshape(C2, C1)
+        da1 = df @ W2
+        dW2 = splitk_wgrad(df, a1).reshape(w2.shape)
+        # layer 1: BN1 + conv(K=3), reductions only
+        W1 = w1.reshape(C1, 3).float().contiguous()
+        nrows = lib.gm3d_embed_partial_rows(3, R, C1)
+        part = torch.empty(nrows, 5 * C1, dtype=f64, device=dev)
+        b1f = b1.float().contiguous()
+        mf = m.float().contiguous()          # keep alive across the launch (raw pointer)
+        _launch("gm3d_pn_layer1_bwd_stats", {"R": R, "C": C1, "dtype": str(adt)}, lib.gm3d_pn_layer1_bwd_stats, _ptr(da1),
+                _ptr(a1), _ptr(x), _ptr(W1), _ptr(b1f), _ptr(mean1), _ptr(rstd1), _ptr(mf), R, C1, _ptr(part), dt_id,
+                _stream())
+        q = torch.empty(5 * C1, dtype=f64, device=dev)
+        _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": 5 * C1}, lib.gm3d_colsum_finish_f64, _ptr(part), nrows,
+                5 * C1, 5 * C1, _ptr(q), _stream())
+        q = q.view(5, C1)
+        t1, t2, Ac = q[0], q[1], q[2:5]                                 # sum g1, sum g1*hhat, sum g1*(x_j - mean_j)
+        # dh0 = k*(g1 - t1/R - hhat*t2/R), k = gamma*rstd;  dW1[c,j] = sum_r dh0*x_j = sum_r dh0*(x_j - m_j)
+        # (sum_r dh0 = 0), sum_r (x_j - m_j) = 0 and sum_r hhat*(x_j - m_j) = rstd * R * (W1 cov)_j:
+        m64, S64 = m.to(f64), S.to(f64)
+        cov = S64 - torch.outer(m64, m64)
+        W64, rs64 = W1.to(f64), rstd1.to(f64)
+        k = g1.to(f64) * rs64
+        dW1 = k[:, None] * (Ac.t() - (t2 * rs64)[:, None] * (W64 @ cov))
+        dg1, dbe1 = t2.float(), t1.float()
+        db1 = torch.zeros_like(b1)                                       # bias in front of BatchNorm: exactly zero
+        return (None, None, dW1.float().reshape(w1.shape), db1, dg1, dbe1, dW2, db2, dW3, db3, dg2, dbe2,
+                dW4.reshape(w4.shape), db4, None, None, None, None, None, None)
+
+
+def run_embed(enc, point_groups):
+    """enc: the Encoder module (parameters in the reference's Conv1d/BatchNorm1d layout)."""
+    c0, bn0, _, c1 = enc.first_conv
+    c2, bn1, _, c3 = enc.second_conv
+    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+        else torch.float32
+    meta = {"adt": adt, "training": enc.training, "eps": bn0.eps, "momentum": bn0.momentum,
+            "grad": torch.is_grad_enabled()}
+    return EmbedFn.apply(point_groups, meta, c0.weight, c0.bias, bn0.weight, bn0.bias, c1.weight, c1.bias, c2.weight,
+                         c2.bias, bn1.weight, bn1.bias, c3.weight, c3.bias, bn0.running_mean, bn0.running_var,
+                         bn0.num_batches_tracked, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked)

@@ -14,6 +14,7 @@ bias / gamma / beta gradient as fused column sums.  The residual stream is fp32,
 (throughput mode) or fp32 (parity mode: same code path, checked to 1e-5 against the reference fixtures).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -42,15 +43,19 @@ class _WeightCache:
 
     def pin(self, model, dtype=torch.bfloat16):
         src = [p for p in model.parameters() if p.dim() >= 2 and p.dtype == torch.float32 and p.is_cuda
-               and p.data_ptr() not in self._pinned]
+               and not self._is_pinned(p)]
         if not src:
             return
         dst = [torch.empty_like(p, dtype=dtype) for p in src]
         for p, d in zip(src, dst):
-            self._pinned[p.data_ptr()] = d
+            self._pinned[p.data_ptr()] = (d, weakref.ref(p))
         self._groups.append(([p.detach() for p in src], dst))
         with torch.no_grad():
             torch._foreach_copy_(dst, self._groups[-1][0])
+
+    def _is_pinned(self, p):
+        hit = self._pinned.get(p.data_ptr())
+        return hit is not None and hit[1]() is p
 
     def refresh(self):
         with torch.no_grad():
@@ -61,17 +66,19 @@ class _WeightCache:
         if w.dtype == dtype:
             return w
         hit = self._pinned.get(w.data_ptr())
-        if hit is not None and hit.dtype == dtype and hit.shape == w.shape:
-            return hit
+        if hit is not None and hit[1]() is w and hit[0].dtype == dtype:
+            return hit[0]
         if torch.cuda.is_current_stream_capturing():
             return w.detach().to(dtype)
         key = (w.data_ptr(), dtype, tuple(w.shape))
         hit = self._c.get(key)
-        if hit is not None and hit[0] == w._version:
+        if hit is not None and hit[0] == w._version and hit[2]() is w:   # same live tensor, unchanged since the cast
             return hit[1]
         with torch.no_grad():
             c = w.detach().to(dtype)
-        self._c[key] = (w._version, c)
+        if len(self._c) > 4096:
+            self._c.clear()
+        self._c[key] = (w._version, c, weakref.ref(w))
         return c
 
 
@@ -189,7 +196,7 @@ class TransformerStackFn(torch.autograd.Function):
         R = B * T
         res = x.reshape(R, C).float().contiguous()
         posa = pos.reshape(R, C).to(adt).contiguous()
-        need = any(ctx.needs_input_grad)   # (forward runs with grad mode off; this is the reliable signal)
+        need = meta["grad"] and any(ctx.needs_input_grad)   # grad mode is off inside forward: captured by run_stack
         y = bias = rs = None
         saved = []
         dev = x.device
@@ -290,7 +297,7 @@ def run_stack(blocks, final_norm, x, pos, training):
         p = getattr(b.drop_path, "drop_prob", 0.0)
         dp.append((M.drop_path_scale(B, p, training, x.device), M.drop_path_scale(B, p, training, x.device)))
     meta = {"num_heads": blocks[0].attn.num_heads, "scale": blocks[0].attn.scale, "eps": blocks[0].norm1.eps,
-            "final_eps": final_norm.eps, "adt": adt, "dp": dp}
+            "final_eps": final_norm.eps, "adt": adt, "dp": dp, "grad": torch.is_grad_enabled()}
     params = []
     for b in blocks:
         params += block_params(b)

@@ -45,6 +45,7 @@ def drop_path_scale(B, p, training, device):
 
 
 FUSED_STACK = True   # False: per-op PyTorch modules below (kept as the in-package cross-check of the fused path)
+FUSED_EMBED = True   # same switch for the mini-PointNet token embed (gm3d_amd/embed.py)
 
 
 class DropPath(nn.Module):
@@ -123,6 +124,10 @@ class Encoder(nn.Module):
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
     def forward(self, point_groups):
+        if FUSED_EMBED and point_groups.is_cuda and (self.training or not torch.is_grad_enabled()
+                                                     or not any(p.requires_grad for p in self.parameters())):
+            from . import embed
+            return embed.run_embed(self, point_groups)
         bs, g, n, _ = point_groups.shape
         c0, bn0, _, c1 = self.first_conv
         c2, bn1, _, c3 = self.second_conv

@@ -146,6 +146,62 @@ int gm3d_bias_gelu_bwd(const void *dg, const void *f, const float *bias, void *d
                        int C, int dtype, gm3d_stream_t stream);
 int gm3d_gelu_partial_rows(int R);
 
+/* ---- Mini-PointNet token embed: streaming passes between its three wide GEMMs (gm3d_amd/csrc/embed.hip) ----
+ * Together with the GEMMs they restate Encoder.forward (Point-MAE_SA3D/models_mae_learn_loss.py:868-899) and its
+ * backward.  Activations are (G groups, K points, C channels) row-major in `dtype`; C % 8 == 0, C <= 1024, K <= 255.
+ * Kernels that reduce over rows write per-workgroup partial rows; gm3d_embed_partial_rows(kind, n, C) gives the
+ * number of rows (kind 0: gm3d_moments3, n = rows; kind 1: (G,K,C) kernels, n = G; kind 2: (R,C) kernels, n = R; kind 3: gm3d_pn_layer1_bwd_stats, n = R),
+ * and gm3d_colsum_finish adds them up. */
+int gm3d_embed_partial_rows(int kind, int n, int C);
+
+/* partial[row][0..2] = sum x_j, [3..8] = sum xx,xy,xz,yy,yz,zz (fp64) of the (R,3) f32 input: BatchNorm statistics of the
+ * K=3 layer are analytic in these moments (first_conv.0/.1, :873-874). */
+int gm3d_moments3(const float *x, int R, double *partial, gm3d_stream_t stream);
+
+/* a1 (R,C1) = relu(x . wf^T + bf): Conv1d(3,128) + BatchNorm (folded into wf (C1,3), bf (C1)) + ReLU (:873-875). */
+int gm3d_pn_layer1_fwd(const float *x, const float *wf, const float *bf, void *a1, int R, int C1, int dtype,
+                       gm3d_stream_t stream);
+
+/* out (G,C) = max over K of in (G,K,C) (+ bias); arg (G,C) uint8 = first maximising k (torch.max(dim)[0], :895,898). */
+int gm3d_group_max_fwd(const void *in, const float *bias, void *out, uint8_t *arg, int G, int K, int C, int dtype,
+                       gm3d_stream_t stream);
+/* din (G,K,C) = dout (G,C) at k == arg, 0 elsewhere (dense; fully written). */
+int gm3d_group_max_bwd(const void *dout, const uint8_t *arg, void *din, int G, int K, int C, int dtype,
+                       gm3d_stream_t stream);
+
+/* BatchNorm over y = y0 (G,K,C) + t (G,C)[group] (second_conv.0/.1 with the concat folded, :896-897,879-880):
+ * partial[row][0][c] = sum y, [1][c] = sum y^2. */
+int gm3d_bn_bcast_stats(const void *y0, const void *t, int G, int K, int C, float *partial, int dtype,
+                        gm3d_stream_t stream);
+/* a2 = relu(y * scale + shift). */
+int gm3d_bn_bcast_apply_relu(const void *y0, const void *t, const float *scale, const float *shift, void *a2,
+                             int G, int K, int C, int dtype, gm3d_stream_t stream);
+/* backward pass 1: g = da2 * [y*scale+shift > 0]; partial[row][0][c] = sum g, [1][c] = sum g * (y-mean)*rstd. */
+int gm3d_bn_bcast_bwd_stats(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
+                            const float *mean, const float *rstd, int G, int K, int C, float *partial, int dtype,
+                            gm3d_stream_t stream);
+/* backward pass 2: dy (G,K,C) = scale * (g - s1/R - yhat * s2/R), dt (G,C) f32 = sum_k dy. */
+int gm3d_bn_bcast_bwd_apply(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
+                            const float *mean, const float *rstd, const float *s1, const float *s2, void *dy,
+                            float *dt, int G, int K, int C, int dtype, gm3d_stream_t stream);
+
+/* df (G,K,C) += dfg (G,C) at k == arg (in place); partial[row][c] = column sums of the result. */
+int gm3d_group_scatter_add(void *df, const void *dfg, const uint8_t *arg, int G, int K, int C, float *partial,
+                           int dtype, gm3d_stream_t stream);
+
+/* Backward reductions of Conv1d(3,C1)+BatchNorm+ReLU: with g1 = da1*[a1>0], hhat = (x.w1+b1-mean)*rstd,
+ * xc = x - xmean (xmean (3) f32): partial[row][q][c] in fp64 (the weight gradient is a small difference of these
+ * sums), q = 0: sum g1, 1: sum g1*hhat, 2..4: sum g1*xc_j; rows = gm3d_embed_partial_rows(3, R, C1); C1 <= 256. */
+int gm3d_pn_layer1_bwd_stats(const void *da1, const void *a1, const float *x, const float *w1, const float *b1,
+                             const float *mean, const float *rstd, const float *xmean, int R, int C1,
+                             double *partial, int dtype, gm3d_stream_t stream);
+/* fp64 second stage: out[c] = sum_r partial[r*pitch + c]. */
+int gm3d_colsum_finish_f64(const double *partial, int nrows, int pitch, int ncols, double *out,
+                           gm3d_stream_t stream);
+
+/* partial[row][c] = column sums of a (R,C) matrix in `dtype`. */
+int gm3d_colsum_partial(const void *m, int R, int C, float *partial, int dtype, gm3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
