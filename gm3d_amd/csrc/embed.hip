@@ -200,10 +200,11 @@ __global__ void bn_bcast_stats_kernel(const T* __restrict__ y0, const T* __restr
     write_partials<2>(acc, sm, partial, C, c, sl, SL);
 }
 
-// a2 = relu((y0 + t[group]) * scale + shift)
+// a2 = act((y0 + t[group]) * scale + shift), act(h) = h > 0 ? h : slope*h  (slope 0: ReLU, 0.2: the head's LeakyReLU)
 template <class T>
 __global__ void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __restrict__ t, const float* __restrict__ scale,
-                                           const float* __restrict__ shift, T* __restrict__ a2, int G, int K, int C) {
+                                           const float* __restrict__ shift, T* __restrict__ a2, int G, int K, int C,
+                                           float slope) {
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
     float sc[8], sh[8];
@@ -217,7 +218,7 @@ __global__ void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __
             const size_t o = ((size_t)g * K + k) * C + c;
             V8<T>::load(y0 + o, v);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { const float h = (v[i] + tv[i]) * sc[i] + sh[i]; v[i] = h > 0.f ? h : 0.f; }
+            for (int i = 0; i < 8; ++i) { const float h = (v[i] + tv[i]) * sc[i] + sh[i]; v[i] = h > 0.f ? h : slope * h; }
             V8<T>::store(a2 + o, v);
         }
     }
@@ -229,7 +230,7 @@ template <class T>
 __global__ void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, int G, int K, int C,
-                                          float* __restrict__ partial) {
+                                          float* __restrict__ partial, float slope) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
@@ -247,7 +248,7 @@ __global__ void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float y = v[i] + tv[i];
-                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : 0.f;
+                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : slope * d[i];
                 acc[0][i] += gg; acc[1][i] += gg * (y - mu[i]) * rs[i];
             }
         }
@@ -262,7 +263,7 @@ __global__ void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                           const float* __restrict__ s1, const float* __restrict__ s2, float inv_rows,
-                                          T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C) {
+                                          T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C, float slope) {
     extern __shared__ float sm[];  // [SL][C]
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
@@ -285,7 +286,7 @@ __global__ void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float y = v[i] + tv[i];
-                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : 0.f;
+                const float gg = (y * sc[i] + sh[i] > 0.f) ? d[i] : slope * d[i];
                 const float r = sc[i] * (gg - m1[i] - (y - mu[i]) * rs[i] * m2[i]);
                 v[i] = r; gs[i] += r;
             }
@@ -424,6 +425,96 @@ __global__ void colsum_partial_kernel(const T* __restrict__ m, int R, int C, flo
     write_partials<1>(acc, sm, partial, C, c, sl, SL);
 }
 
+
+// ------------------------------------------------------------------ K=3 linear + GELU (pos_embed first layer)
+__device__ __forceinline__ float gelu3(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu3_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+}
+
+// out (R,C) = GELU(x (R,3) . w (C,3)^T + b): pos_embed[0..1] (models_mae_learn_loss.py:104-108) without a K=3 GEMM
+template <class T>
+__global__ __launch_bounds__(256) void lin3_gelu_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, T* __restrict__ out, int R, int C) {
+    const int tpr = C >> 3;
+    const size_t total = (size_t)R * tpr;
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (size_t)gridDim.x * 256) {
+        const size_t r = t / tpr;
+        const int c = (int)(t - r * tpr) * 8;
+        const float px = x[r * 3], py = x[r * 3 + 1], pz = x[r * 3 + 2];
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu3(px * w[(c + i) * 3] + py * w[(c + i) * 3 + 1] + pz * w[(c + i) * 3 + 2] + b[c + i]);
+        V8<T>::store(out + r * C + c, v);
+    }
+}
+
+// dpre = dout * GELU'(pre); partial[block][q][c] (fp64): q=0 sum dpre (bias grad), q=1..3 sum dpre * x_j (weight grad)
+template <class T>
+__global__ void lin3_gelu_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
+                                     const float* __restrict__ b, int R, int C, double* __restrict__ partial) {
+    extern __shared__ double smd[];
+    const int tpr = C >> 3, SL = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+    float wx[8], wy[8], wz[8], bb[8];
+    double acc[4][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        wx[i] = w[(c + i) * 3]; wy[i] = w[(c + i) * 3 + 1]; wz[i] = w[(c + i) * 3 + 2]; bb[i] = b[c + i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q][i] = 0.0;
+    }
+    for (size_t r = (size_t)blockIdx.x * SL + sl; r < (size_t)R; r += (size_t)gridDim.x * SL) {
+        float d[8];
+        V8<T>::load(dout + r * C + c, d);
+        const float px = x[r * 3], py = x[r * 3 + 1], pz = x[r * 3 + 2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const double g = (double)(d[i] * gelu3_grad(px * wx[i] + py * wy[i] + pz * wz[i] + bb[i]));
+            acc[0][i] += g; acc[1][i] += g * px; acc[2][i] += g * py; acc[3][i] += g * pz;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) smd[(size_t)sl * 4 * C + q * C + c + i] = acc[q][i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < 4 * C; t += blockDim.x) {
+        double s = 0.0;
+        for (int s2 = 0; s2 < SL; ++s2) s += smd[(size_t)s2 * 4 * C + t];
+        partial[(size_t)blockIdx.x * 4 * C + t] = s;
+    }
+}
+
+// ------------------------------------------------------------------ pairwise ranking loss (forward_learning_loss)
+// models_mae_learn_loss.py:795-805: pos[i,j] = t_j > t_i, neg[i,j] = t_j < t_i, D = p_j - p_i,
+//   loss = sum(-pos*log(sig(D)+1e-6) - neg*log(1-sig(D)+1e-6)) / sum(pos|neg).   One wave per sample, M <= 64.
+// out[b][0] = sum of the pair terms, out[b][1] = number of ordered pairs; dp[b][k] = d(sum)/dp_k (unnormalised).
+__global__ __launch_bounds__(64) void rank_loss_kernel(const float* __restrict__ p, const float* __restrict__ t, int M,
+                                                       float* __restrict__ out, float* __restrict__ dp) {
+    const int b = blockIdx.x, j = threadIdx.x;
+    const float pj = j < M ? p[(size_t)b * M + j] : 0.f, tj = j < M ? t[(size_t)b * M + j] : 0.f;
+    float ls = 0.f, cnt = 0.f, g = 0.f;
+    for (int i = 0; i < M; ++i) {
+        const float pi = __shfl(pj, i), ti = __shfl(tj, i);
+        if (j < M) {
+            // pair (i, j): D = p_j - p_i
+            const float sg = 1.0f / (1.0f + __expf(-(pj - pi)));
+            const float ds = sg * (1.0f - sg);
+            if (tj > ti) { ls -= __logf(sg + 1e-6f); cnt += 1.f; g -= ds / (sg + 1e-6f); }
+            else if (tj < ti) { ls -= __logf(1.0f - sg + 1e-6f); cnt += 1.f; g += ds / (1.0f - sg + 1e-6f); }
+            // pair (j, i): D' = p_i - p_j, contributes -dL/dD' to p_j
+            const float s2 = 1.0f / (1.0f + __expf(-(pi - pj)));
+            const float d2 = s2 * (1.0f - s2);
+            if (ti > tj) g += d2 / (s2 + 1e-6f);
+            else if (ti < tj) g -= d2 / (1.0f - s2 + 1e-6f);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); cnt += __shfl_xor(cnt, o); }
+    if (j == 0) { out[(size_t)b * 2] = ls; out[(size_t)b * 2 + 1] = cnt; }
+    if (j < M) dp[(size_t)b * M + j] = g;
+}
+
 static inline bool chan_ok(int C) { return C >= 8 && C % 8 == 0 && C <= 1024; }
 static inline int threads_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; if (sl < 1) sl = 1; return sl * tpr; }
 static inline int slices_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; return sl < 1 ? 1 : sl; }
@@ -526,7 +617,7 @@ extern "C" int gm3d_bn_bcast_stats(const void* y0, const void* t, int G, int K, 
 }
 
 extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const float* scale, const float* shift, void* a2,
-                                        int G, int K, int C, int dtype, gm3d_stream_t stream) {
+                                        int G, int K, int C, float slope, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
@@ -534,16 +625,16 @@ extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const flo
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
-                                     (const bf16_t*)y0, (const bf16_t*)t, scale, shift, (bf16_t*)a2, G, K, C),
+                                     (const bf16_t*)y0, (const bf16_t*)t, scale, shift, (bf16_t*)a2, G, K, C, slope),
                   hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
-                                     (const float*)y0, (const float*)t, scale, shift, (float*)a2, G, K, C));
+                                     (const float*)y0, (const float*)t, scale, shift, (float*)a2, G, K, C, slope));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
 
 extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const void* t, const float* scale,
                                        const float* shift, const float* mean, const float* rstd, int G, int K, int C,
-                                       float* partial, int dtype, gm3d_stream_t stream) {
+                                       float* partial, float slope, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
@@ -552,16 +643,16 @@ extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const vo
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
-                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, G, K, C, partial),
+                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, G, K, C, partial, slope),
                   hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
-                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, G, K, C, partial));
+                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, G, K, C, partial, slope));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
 
 extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const void* t, const float* scale,
                                        const float* shift, const float* mean, const float* rstd, const float* s1,
-                                       const float* s2, void* dy, float* dt, int G, int K, int C, int dtype,
+                                       const float* s2, void* dy, float* dt, int G, int K, int C, float slope, int dtype,
                                        gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
@@ -573,10 +664,10 @@ extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const vo
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
                                      (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, s1, s2,
-                                     inv_rows, (bf16_t*)dy, dt, G, K, C),
+                                     inv_rows, (bf16_t*)dy, dt, G, K, C, slope),
                   hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
                                      (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, s1, s2,
-                                     inv_rows, (float*)dy, dt, G, K, C));
+                                     inv_rows, (float*)dy, dt, G, K, C, slope));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -640,6 +731,49 @@ extern "C" int gm3d_colsum_partial(const void* m, int R, int C, float* partial, 
                                      (const bf16_t*)m, R, C, partial),
                   hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(row_grid(R, C)), dim3(threads_for(C)), lds, st,
                                      (const float*)m, R, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_lin3_gelu_fwd(const float* x, const float* w, const float* b, void* out, int R, int C, int dtype,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!x || !w || !b || !out || R < 1) return GM3D_EINVAL;
+    if (!chan_ok(C)) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const size_t total = (size_t)R * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(lin3_gelu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x, w, b, (bf16_t*)out, R, C),
+                  hipLaunchKernelGGL(lin3_gelu_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, x, w, b, (float*)out, R, C));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_lin3_gelu_bwd(const void* dout, const float* x, const float* w, const float* b, int R, int C,
+                                  double* partial, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dout || !x || !w || !b || !partial || R < 1) return GM3D_EINVAL;
+    if (!chan_ok(C) || C > 256) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const int tpr = C / 8, sl = 8;
+    const size_t lds = (size_t)sl * 4 * C * sizeof(double);
+    int grid = (R + sl - 1) / sl; grid = grid > 1024 ? 1024 : grid;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(lin3_gelu_bwd_kernel<bf16_t>, dim3(grid), dim3(sl * tpr), lds, st, (const bf16_t*)dout, x, w, b, R, C, partial),
+                  hipLaunchKernelGGL(lin3_gelu_bwd_kernel<float>, dim3(grid), dim3(sl * tpr), lds, st, (const float*)dout, x, w, b, R, C, partial));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_rank_loss(const float* pred, const float* target, int B, int M, float* out, float* dpred,
+                              gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!pred || !target || !out || !dpred || B < 1 || M < 1) return GM3D_EINVAL;
+    if (M > 64) return GM3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(rank_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, target, M, out, dpred);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

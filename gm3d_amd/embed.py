@@ -91,7 +91,7 @@ class EmbedFn(torch.autograd.Function):
                     _ptr(mom9), _stream())
             mom9 = mom9 / R
             m = mom9[:3]
-            S = torch.stack([mom9[[3, 4, 5]], mom9[[4, 6, 7]], mom9[[5, 7, 8]]])
+            S = torch.stack([mom9[i] for i in (3, 4, 5, 4, 6, 7, 5, 7, 8)]).view(3, 3)   # (no index tensors: H2D copies cannot be captured)
             cov = S - torch.outer(m, m)
             W64 = W1.detach().to(f64)
             mean1 = W64 @ m + b1.detach().to(f64)
@@ -141,7 +141,7 @@ class EmbedFn(torch.autograd.Function):
         shift2 = (be2.detach().to(f64) - mean2 * g2.detach().to(f64) * rstd2).float()
         a2 = torch.empty(R, C3, dtype=adt, device=dev)
         _launch("gm3d_bn_bcast_apply_relu", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
-                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, dt_id, _stream())
+                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, 0.0, dt_id, _stream())
         # ---- conv4 + max-pool ----
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         z = a2 @ W4.t()
@@ -187,14 +187,14 @@ class EmbedFn(torch.autograd.Function):
         part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
         _launch("gm3d_bn_bcast_bwd_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats,
                 _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), BG, K, C3, _ptr(part),
-                dt_id, _stream())
+                0.0, dt_id, _stream())
         s12 = _finish(part, nrows, 2 * C3)
         s1, s2 = s12[:C3], s12[C3:]
         dy = torch.empty(R, C3, dtype=adt, device=dev)
         dt = torch.empty(BG, C3, dtype=torch.float32, device=dev)
         _launch("gm3d_bn_bcast_bwd_apply", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply,
                 _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), _ptr(s1), _ptr(s2),
-                _ptr(dy), _ptr(dt), BG, K, C3, dt_id, _stream())
+                _ptr(dy), _ptr(dt), BG, K, C3, 0.0, dt_id, _stream())
         dg2, dbe2 = s2, s1
         # conv3: local part on rows, global part per group
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)

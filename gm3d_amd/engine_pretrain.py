@@ -289,22 +289,30 @@ class GraphedPretrainStep:
     reused -- reproduced without any of our code by tools/graph_reduce_test2.py.  The step is only replay-safe
     where every such reduction is one of our own kernels; tests/test_gpu_graph.py compares replay against eager."""
 
-    def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3):
+    def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3, augment=True,
+                 inject_mask_noise=False):
+        """inject_mask_noise=True: the (B,L) ranking noise of generate_mask becomes a static input filled by the caller
+        (deterministic replays for the tests); otherwise it is drawn inside the graph."""
         self.static_in = example.clone()
+        L = (model.module if hasattr(model, "module") else model).num_group
+        self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
         self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
+        kw = dict(augment=augment, mask_noise=self.static_noise)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup_iters):
-                pretrain_step(model, model_ema, optimizer, self.static_in.clone(), epoch, args)
+                pretrain_step(model, model_ema, optimizer, self.static_in.clone(), epoch, args, **kw)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args)
+            self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args, **kw)
 
-    def __call__(self, samples):
+    def __call__(self, samples, mask_noise=None):
         self.static_in.copy_(samples, non_blocking=True)
+        if self.static_noise is not None:
+            self.static_noise.copy_(mask_noise, non_blocking=True)
         self.graph.replay()
         return self.out
 

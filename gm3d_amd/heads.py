@@ -1,0 +1,218 @@
+"""The small layers around the transformer stacks as hand-written autograd nodes whose every row reduction is one of
+our own kernels (deterministic two-stage column sums; no PyTorch multi-block reduce_kernel, which is what makes
+the whole step safe to replay as a hipGraph on this stack -- see GraphedPretrainStep):
+
+  PosEmbedFn      pos_embed = Linear(3,128) -> GELU -> Linear(128,384)        (P/models_mae_learn_loss.py:104-108)
+  LinearBiasFn    increase_dim_just_network_without_feature = Conv1d(384,96)   (P/:169-176, used at :662)
+  LossPredHeadFn  increase_dim_2 = Conv1d(384,1024) -> BN1d -> LeakyReLU(0.2) -> Conv1d(1024,384), then mean(-1)
+                  (P/:152-158, :668, :677), last conv + mean folded into one 1024-vector
+  ExpandRowsFn    mask_token.expand(B, N, -1)                                  (P/:653)
+  rank_loss       forward_learning_loss(relative=True)                          (P/:795-805)
+"""
+import torch
+
+from ._capi import lib
+from .embed import _finish, colsum, splitk_wgrad
+from .fused import weight_cache
+from .ops import _launch, _ptr, _stream, _DT
+
+
+def _adt():
+    return torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+        else torch.float32
+
+
+def _finish64(part, nrows, ncols):
+    out = torch.empty(ncols, dtype=torch.float64, device=part.device)
+    _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": ncols}, lib.gm3d_colsum_finish_f64, _ptr(part), nrows, ncols,
+            ncols, _ptr(out), _stream())
+    return out
+
+
+class LinearBiasFn(torch.autograd.Function):
+    """y = x @ W^T + b on rows; x (R,K) in adt, W (N,K[,1]) fp32 master, b (N)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, adt):
+        with torch.autocast("cuda", enabled=False):
+            shp = x.shape
+            x2 = x.reshape(-1, shp[-1]).to(adt).contiguous()
+            W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
+            y = torch.addmm(b.detach().to(adt), x2, W.t())
+            ctx.save_for_backward(x2, w)
+            ctx.adt, ctx.shp, ctx.xdt = adt, shp, x.dtype
+            return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        with torch.autocast("cuda", enabled=False):
+            x2, w = ctx.saved_tensors
+            adt = ctx.adt
+            dy2 = dy.reshape(-1, dy.shape[-1]).to(adt).contiguous()
+            W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
+            dx = (dy2 @ W).view(ctx.shp).to(ctx.xdt)
+            dW = splitk_wgrad(dy2, x2).reshape(w.shape)
+            db = colsum(dy2, adt)
+            return dx, dW, db, None
+
+
+class PosEmbedFn(torch.autograd.Function):
+    """center (B,G,3) f32 -> (B,G,384) adt.  The K=3 layer and its GELU are one streaming kernel; its backward is a
+    pure reduction (xyz carries no gradient)."""
+
+    @staticmethod
+    def forward(ctx, center, w0, b0, w1, b1, adt):
+        with torch.autocast("cuda", enabled=False):
+            B, G, _ = center.shape
+            R, C = B * G, w0.shape[0]
+            x = center.reshape(R, 3).float().contiguous()
+            w0f, b0f = w0.detach().float().contiguous(), b0.detach().float().contiguous()
+            h = torch.empty(R, C, dtype=adt, device=x.device)
+            _launch("gm3d_lin3_gelu_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_fwd, _ptr(x), _ptr(w0f),
+                    _ptr(b0f), _ptr(h), R, C, _DT[adt], _stream())
+            W1 = weight_cache.get(w1, adt)
+            out = torch.addmm(b1.detach().to(adt), h, W1.t())
+            ctx.save_for_backward(x, h, w0f, b0f, w1)
+            ctx.adt, ctx.dims = adt, (B, G, R, C)
+            return out.view(B, G, -1)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.autocast("cuda", enabled=False):
+            x, h, w0f, b0f, w1 = ctx.saved_tensors
+            adt = ctx.adt
+            B, G, R, C = ctx.dims
+            d = dout.reshape(R, -1).to(adt).contiguous()
+            W1 = weight_cache.get(w1, adt)
+            dW1 = splitk_wgrad(d, h)
+            db1 = colsum(d, adt)
+            dh = (d @ W1).contiguous()
+            nrows = lib.gm3d_embed_partial_rows(3, R, C)
+            part = torch.empty(nrows, 4 * C, dtype=torch.float64, device=x.device)
+            _launch("gm3d_lin3_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_bwd, _ptr(dh), _ptr(x),
+                    _ptr(w0f), _ptr(b0f), R, C, _ptr(part), _DT[adt], _stream())
+            q = _finish64(part, nrows, 4 * C).view(4, C)
+            return None, q[1:4].t().float().contiguous(), q[0].float(), dW1, db1, None
+
+
+class LossPredHeadFn(torch.autograd.Function):
+    """x (B,L,384) -> (B,L) f32: Conv1d(384,1024) -> BatchNorm1d (batch statistics over B*L rows in train mode) ->
+    LeakyReLU(0.2) -> [Conv1d(1024,384) ; mean over its 384 outputs] as one 1024-vector."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, gamma, beta, w1, b1, rm, rv, nbt, meta):
+        with torch.autocast("cuda", enabled=False):
+            adt, training, eps, mom, slope = meta["adt"], meta["training"], meta["eps"], meta["momentum"], meta["slope"]
+            B, L, Cin = x.shape
+            R, C = B * L, w0.shape[0]
+            K = 32 if R % 32 == 0 else 1
+            G = R // K
+            dev = x.device
+            f64 = torch.float64
+            x2 = x.reshape(R, Cin).to(adt).contiguous()
+            W0 = weight_cache.get(w0, adt).reshape(C, Cin)
+            y0 = x2 @ W0.t()
+            t = b0.detach().to(adt).unsqueeze(0).expand(G, C).contiguous()
+            if training:
+                nrows = lib.gm3d_embed_partial_rows(1, G, C)
+                part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
+                _launch("gm3d_bn_bcast_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
+                        _ptr(t), G, K, C, _ptr(part), _DT[adt], _stream())
+                st = _finish(part, nrows, 2 * C).to(f64) / R
+                mean = st[:C]
+                var = (st[C:] - mean * mean).clamp_min(0.0)
+                with torch.no_grad():
+                    rm.mul_(1 - mom).add_(mean.to(rm.dtype), alpha=mom)
+                    rv.mul_(1 - mom).add_((var * (R / (R - 1.0))).to(rv.dtype), alpha=mom)
+                    nbt.add_(1)
+            else:
+                mean, var = rm.to(f64), rv.to(f64)
+            rstd = torch.rsqrt(var + eps)
+            scale = (gamma.detach().to(f64) * rstd).float()
+            shift = (beta.detach().to(f64) - mean * gamma.detach().to(f64) * rstd).float()
+            a = torch.empty(R, C, dtype=adt, device=dev)
+            _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
+                    _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
+            W1 = w1.detach().reshape(w1.shape[0], C).float()
+            wv = W1.mean(dim=0)                                   # (C,) -- reduction over 384 rows per output: small
+            out = (a @ wv.to(adt)).float() + b1.detach().float().mean()
+            if meta["grad"] and any(ctx.needs_input_grad):
+                if not training:
+                    raise NotImplementedError("LossPredHeadFn backward is implemented for train-mode BatchNorm only")
+                ctx.save_for_backward(x2, y0, t, a, w0, gamma, w1, wv, mean.float(), rstd.float(), scale, shift)
+                ctx.meta, ctx.dims, ctx.xdt = meta, (B, L, Cin, R, C, G, K), x.dtype
+            return out.view(B, L)
+
+    @staticmethod
+    def backward(ctx, dout):
+        with torch.autocast("cuda", enabled=False):
+            x2, y0, t, a, w0, gamma, w1, wv, mean, rstd, scale, shift = ctx.saved_tensors
+            meta = ctx.meta
+            adt, slope = meta["adt"], meta["slope"]
+            B, L, Cin, R, C, G, K = ctx.dims
+            dev = dout.device
+            d = dout.reshape(R).float().contiguous()
+            nout = w1.shape[0]
+            # out = a @ wv + mean(b1), wv = mean_rows(W1)
+            dwv = (a.t() @ d.to(adt)).float()                                        # (C,)  GEMV, not a reduce_kernel
+            dW1 = (dwv / nout).unsqueeze(0).expand(nout, C).reshape(w1.shape).contiguous()
+            db1 = (d.sum() / nout).expand(nout).contiguous()                       # R <= a few thousand elements
+            da = (d.unsqueeze(1) * wv.unsqueeze(0)).to(adt)                         # (R,C)
+            nrows = lib.gm3d_embed_partial_rows(1, G, C)
+            part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
+            _launch("gm3d_bn_bcast_bwd_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats,
+                    _ptr(da), _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), G, K, C, _ptr(part),
+                    float(slope), _DT[adt], _stream())
+            s12 = _finish(part, nrows, 2 * C)
+            s1, s2 = s12[:C], s12[C:]
+            dy = torch.empty(R, C, dtype=adt, device=dev)
+            dt = torch.empty(G, C, dtype=torch.float32, device=dev)
+            _launch("gm3d_bn_bcast_bwd_apply", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply,
+                    _ptr(da), _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2),
+                    _ptr(dy), _ptr(dt), G, K, C, float(slope), _DT[adt], _stream())
+            W0 = weight_cache.get(w0, adt).reshape(C, Cin)
+            dx = (dy @ W0).view(B, L, Cin).to(ctx.xdt)
+            dW0 = splitk_wgrad(dy, x2).reshape(w0.shape)
+            db0 = colsum(dt, torch.float32)
+            return dx, dW0, db0, s2, s1, dW1, db1, None, None, None, None
+
+
+class ExpandRowsFn(torch.autograd.Function):
+    """token (1,1,C) -> (B,N,C); backward = column sum over the B*N rows with our two-stage kernel."""
+
+    @staticmethod
+    def forward(ctx, token, B, N, dtype):
+        ctx.tdt = token.dtype
+        return token.to(dtype).expand(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, g):
+        with torch.autocast("cuda", enabled=False):
+            C = g.shape[-1]
+            g2 = g.reshape(-1, C).contiguous()
+            return colsum(g2, g2.dtype).view(1, 1, C).to(ctx.tdt), None, None, None
+
+
+class _RankLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        with torch.autocast("cuda", enabled=False):
+            B, M = pred.shape
+            p = pred.detach().float().contiguous()
+            t = target.detach().float().contiguous()
+            out = torch.empty(B, 2, dtype=torch.float32, device=pred.device)
+            dp = torch.empty(B, M, dtype=torch.float32, device=pred.device)
+            _launch("gm3d_rank_loss", {"B": B, "M": M}, lib.gm3d_rank_loss, _ptr(p), _ptr(t), B, M, _ptr(out), _ptr(dp), _stream())
+            tot = out.sum(dim=0)                                 # B rows: single-block reduction
+            ctx.save_for_backward(dp, tot)
+            ctx.pdt = pred.dtype
+            return tot[0] / tot[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        dp, tot = ctx.saved_tensors
+        return (dp * (g / tot[1])).to(ctx.pdt), None
+
+
+def rank_loss(pred, target):
+    return _RankLoss.apply(pred, target)

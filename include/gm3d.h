@@ -173,17 +173,18 @@ int gm3d_group_max_bwd(const void *dout, const uint8_t *arg, void *din, int G, i
  * partial[row][0][c] = sum y, [1][c] = sum y^2. */
 int gm3d_bn_bcast_stats(const void *y0, const void *t, int G, int K, int C, float *partial, int dtype,
                         gm3d_stream_t stream);
-/* a2 = relu(y * scale + shift). */
+/* a2 = act(y * scale + shift), act(h) = h > 0 ? h : slope*h  (slope 0: ReLU of the embed; 0.2: LeakyReLU of the
+ * loss-predictor head increase_dim_2, :152-158). */
 int gm3d_bn_bcast_apply_relu(const void *y0, const void *t, const float *scale, const float *shift, void *a2,
-                             int G, int K, int C, int dtype, gm3d_stream_t stream);
+                             int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
 /* backward pass 1: g = da2 * [y*scale+shift > 0]; partial[row][0][c] = sum g, [1][c] = sum g * (y-mean)*rstd. */
 int gm3d_bn_bcast_bwd_stats(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
-                            const float *mean, const float *rstd, int G, int K, int C, float *partial, int dtype,
-                            gm3d_stream_t stream);
+                            const float *mean, const float *rstd, int G, int K, int C, float *partial, float slope,
+                            int dtype, gm3d_stream_t stream);
 /* backward pass 2: dy (G,K,C) = scale * (g - s1/R - yhat * s2/R), dt (G,C) f32 = sum_k dy. */
 int gm3d_bn_bcast_bwd_apply(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
                             const float *mean, const float *rstd, const float *s1, const float *s2, void *dy,
-                            float *dt, int G, int K, int C, int dtype, gm3d_stream_t stream);
+                            float *dt, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
 
 /* df (G,K,C) += dfg (G,C) at k == arg (in place); partial[row][c] = column sums of the result. */
 int gm3d_group_scatter_add(void *df, const void *dfg, const uint8_t *arg, int G, int K, int C, float *partial,
@@ -201,6 +202,19 @@ int gm3d_colsum_finish_f64(const double *partial, int nrows, int pitch, int ncol
 
 /* partial[row][c] = column sums of a (R,C) matrix in `dtype`. */
 int gm3d_colsum_partial(const void *m, int R, int C, float *partial, int dtype, gm3d_stream_t stream);
+
+/* out (R,C) = GELU(x (R,3) . w (C,3)^T + b): first layer + activation of pos_embed (models_mae_learn_loss.py:104-108). */
+int gm3d_lin3_gelu_fwd(const float *x, const float *w, const float *b, void *out, int R, int C, int dtype,
+                       gm3d_stream_t stream);
+/* its backward reductions: dpre = dout * GELU'(pre); partial[row][q][c] fp64, q = 0: sum dpre, 1..3: sum dpre * x_j;
+ * rows = gm3d_embed_partial_rows(3, R, C); C <= 256. */
+int gm3d_lin3_gelu_bwd(const void *dout, const float *x, const float *w, const float *b, int R, int C,
+                       double *partial, int dtype, gm3d_stream_t stream);
+
+/* Pairwise ranking loss of forward_learning_loss(relative=True) (models_mae_learn_loss.py:795-805), per sample:
+ * out (B,2) f32 = [sum of pair terms, number of ordered pairs]; dpred (B,M) = d(sum of pair terms)/d pred.  M <= 64. */
+int gm3d_rank_loss(const float *pred, const float *target, int B, int M, float *out, float *dpred,
+                   gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

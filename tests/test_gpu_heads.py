@@ -1,0 +1,95 @@
+"""-m gpu: gm3d_amd/heads.py (pos_embed, pix head, loss-predictor head, mask-token expand, ranking loss) against the
+per-op PyTorch modules / expressions of the same package, fp32 at 1e-5 and bf16 against the fp32 result."""
+import copy
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def err(a, b):
+    return float((a.detach().double() - b.detach().double()).abs().max())
+
+
+def amax(a):
+    return float(a.detach().abs().max())
+
+
+def test_rank_loss_matches_expression():
+    from gm3d_amd import models_mae_learn_loss as M
+    m = M.MaskedAutoencoderViT.__new__(M.MaskedAutoencoderViT)
+    torch.manual_seed(0)
+    p = torch.randn(9, 39, device="cuda", requires_grad=True)
+    t = torch.rand(9, 39, device="cuda")
+    t[:, 5] = t[:, 6]
+    outs = {}
+    for fused in (False, True):
+        M.FUSED_HEADS = fused
+        p.grad = None
+        loss = M.MaskedAutoencoderViT.forward_learning_loss(m, p, None, t, relative=True)
+        (loss * 3.0).backward()
+        outs[fused] = (loss.detach(), p.grad.clone())
+    M.FUSED_HEADS = True
+    assert err(outs[True][0], outs[False][0]) <= 1e-5 * amax(outs[False][0])
+    assert err(outs[True][1], outs[False][1]) <= 2e-5 * amax(outs[False][1])
+    nan = M.MaskedAutoencoderViT.forward_learning_loss(m, p, None, torch.ones_like(t), relative=True)
+    assert torch.isnan(nan)          # 0/0 like the reference (engine exits on it)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_heads_match_modules(train):
+    from gm3d_amd import models_mae_learn_loss as M
+    torch.manual_seed(3)
+    base = M.mae_vit_base_patch16_dec512d8b().cuda()
+    with torch.no_grad():
+        bn = base.increase_dim_2[1]
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3); bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 1.5)
+        base.mask_token.normal_()
+    B, L = 6, 64
+    center = torch.rand(B, L, 3, device="cuda") - 0.5
+    xr = torch.randn(B, L, 384, device="cuda")
+    w_pos, w_pix, w_lp = (torch.randn(B, L, 384, device="cuda"), torch.randn(B, L, 96, device="cuda"), torch.randn(B, L, device="cuda"))
+
+    def run(fused, bf16):
+        m = copy.deepcopy(base).train(train)
+        M.FUSED_HEADS = fused
+        x = xr.clone().requires_grad_(train)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16), torch.set_grad_enabled(train):
+            pos = m.embed_pos(center)
+            if fused:
+                from gm3d_amd import heads
+                pix = heads.LinearBiasFn.apply(x, m.increase_dim_just_network_without_feature[0].weight,
+                                               m.increase_dim_just_network_without_feature[0].bias, heads._adt())
+                tok = heads.ExpandRowsFn.apply(m.mask_token, B, 5, pos.dtype)
+            else:
+                c = m.increase_dim_just_network_without_feature[0]
+                pix = torch.nn.functional.linear(x, c.weight.squeeze(-1), c.bias)
+                tok = m.mask_token.expand(B, 5, -1).to(pos.dtype)
+            lp = m._loss_pred_head(x)
+            if train:
+                ((pos.float() * w_pos).sum() + (pix.float() * w_pix).sum() + (lp.float() * w_lp).sum()
+                 + (tok.float() * w_pos[:, :5]).sum()).backward()
+        M.FUSED_HEADS = True
+        grads = {k: p.grad.detach().double() for k, p in m.named_parameters() if p.grad is not None}
+        if train:
+            grads["x"] = x.grad.detach().double()
+        bufs = {k: b.detach().double() for k, b in m.increase_dim_2.named_buffers()}
+        return {"pos": pos.detach().double(), "pix": pix.detach().double(), "lp": lp.detach().double()}, grads, bufs
+
+    ro, rg, rb = run(False, False)
+    fo, fg, fb = run(True, False)
+    for k in ro:
+        assert err(fo[k], ro[k]) <= 1e-5 * amax(ro[k]), k
+    gn = sum(float(v.pow(2).sum()) for v in rg.values()) ** 0.5 if rg else 0.0
+    assert set(fg) == set(rg)
+    for k in rg:
+        assert err(fg[k], rg[k]) <= 3e-5 * amax(rg[k]) + 1e-6 * gn, k
+    for k in rb:
+        assert err(fb[k], rb[k]) <= 1e-5 * amax(rb[k]) + 1e-7, k
+    mo, mg, _ = run(False, True)
+    bo, bg, _ = run(True, True)
+    for k in ro:
+        assert err(bo[k], ro[k]) <= 2 * err(mo[k], ro[k]) + 2e-2 * amax(ro[k]), k
+    for k in rg:
+        assert err(bg[k], rg[k]) <= 2 * err(mg[k], rg[k]) + 2e-2 * amax(rg[k]) + 1e-6 * gn, k
