@@ -101,11 +101,8 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--bucket-mb", type=int, default=32)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one captured hipGraph (single GPU).  OFF by default: on this ROCm 7.2 / "
-                         "torch 2.10 stack PyTorch's multi-block reduce_kernel returns stale results from the 2nd replay on "
-                         "(tools/graph_reduce_test2.py reproduces it without any gm3d code), so a captured step is only "
-                         "trustworthy once every reduction in it is one of our own kernels")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="eager launches instead of hipGraph replay (the step is ~1000 launches: eager is host-bound)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -128,7 +125,7 @@ def main():
     torch.manual_seed(0)                      # identical random-init weights on every rank
     model = M.mae_vit_base_patch16_dec512d8b(norm_pix_loss=False).to(device).train()
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
-    use_graph = world == 1 and args.graph
+    use_graph = not args.no_graph
     optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, capturable=use_graph)
     grad_sync = E.GradSync(model.parameters(), bucket_bytes=args.bucket_mb << 20) if world > 1 else None
     step_args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=not args.fp32, accum_iter=1,
@@ -159,7 +156,7 @@ def main():
     dominant = max((n for n in psum if algorithmic(n, psum[n]["meta"])), key=lambda n: psum[n]["total_ms"])
 
     if use_graph:
-        graphed = E.GraphedPretrainStep(model, model_ema, optimizer, step_args, pool[0], args.epoch)
+        graphed = E.GraphedPretrainStep(model, model_ema, optimizer, step_args, pool[0], args.epoch, grad_sync=grad_sync)
 
         def step(i):
             E.adjust_learning_rate(optimizer, args.epoch + i / 1000.0, step_args)
@@ -232,7 +229,7 @@ def main():
                          "frac": achieved / peak, "traffic": None,
                          "avg_launch_us": tsum["avg_ms"] * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
-            "execution": "hipGraph replay" if use_graph else "eager",
+            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph else "eager",
             "hip_kernels_ms_per_step": per_step,
             "loss": loss,
         }

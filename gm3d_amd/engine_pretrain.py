@@ -157,6 +157,7 @@ class GradSync:
         self._works = []
         self._launched = [False] * len(self.buckets)
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.overlap = True   # False: hooks stay silent and finish() issues every bucket (used around captured graphs)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
@@ -186,6 +187,8 @@ class GradSync:
         self._works.append((dist.all_reduce(flat, op=op, group=self.group, async_op=True), b))
 
     def _hook(self, p):
+        if not self.overlap:
+            return
         b = self._owner[p]
         self._pending[b] -= 1
         if self._pending[b] == 0 and not self._launched[b]:
@@ -229,10 +232,10 @@ def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
 
 
 # --------------------------------------------------------------------------- the step
-def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=None, mask_noise=None,
-                  augment=True, aug_draws=None, clip_grad=5.0):
-    """One iteration of P/engine_pretrain.py:77-212.  `samples` (B,N,3) f32 on the GPU (modified in
-    place by the augmentation, like the reference).  Returns device tensors only -- no host sync."""
+def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None, mask_noise=None, augment=True,
+                          aug_draws=None, optimizer=None):
+    """First half of P/engine_pretrain.py:77-197: augment -> teacher -> mask -> student -> losses -> backward.
+    Leaves the gradients in p.grad (views of GradSync's flat buckets when data-parallel)."""
     raw = model.module if hasattr(model, "module") else model
     teacher = model_ema.ema
     L = raw.num_group
@@ -264,17 +267,36 @@ def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=N
     total = (loss + loss_learn) / getattr(args, "accum_iter", 1)         # P/:190,195
     if grad_sync is not None:
         grad_sync.zero_grad()
-    else:
+    elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
+    else:
+        for p in raw.parameters():
+            p.grad = None
     total.backward()
-    if grad_sync is not None:
-        grad_sync.finish()
-    grad_norm = torch.nn.utils.clip_grad_norm_(raw.parameters(), clip_grad, foreach=True)  # misc.py:262-264
+    return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
+            "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
+            "teacher_loss_pred": outs_ema["loss_pred"]}
+
+
+def step_update(model, model_ema, optimizer, clip_grad=5.0):
+    """Second half (P/util/misc.py:262-266 + P/engine_pretrain.py:208-212): clip -> AdamW -> EMA."""
+    raw = model.module if hasattr(model, "module") else model
+    grad_norm = torch.nn.utils.clip_grad_norm_(raw.parameters(), clip_grad, foreach=True)
     optimizer.step()
     model_ema.update(raw)
-    return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
-            "loss_mse": loss_mse.detach(), "grad_norm": grad_norm, "mask": bool_masked_pos,
-            "matrix": loss_outs["matrix"].detach(), "teacher_loss_pred": outs_ema["loss_pred"]}
+    return grad_norm
+
+
+def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=None, mask_noise=None,
+                  augment=True, aug_draws=None, clip_grad=5.0):
+    """One iteration of P/engine_pretrain.py:77-212.  `samples` (B,N,3) f32 on the GPU (modified in
+    place by the augmentation, like the reference).  Returns device tensors only -- no host sync."""
+    out = step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=grad_sync, mask_noise=mask_noise,
+                                augment=augment, aug_draws=aug_draws, optimizer=optimizer)
+    if grad_sync is not None:
+        grad_sync.finish()
+    out["grad_norm"] = step_update(model, model_ema, optimizer, clip_grad)
+    return out
 
 
 class GraphedPretrainStep:
@@ -290,14 +312,19 @@ class GraphedPretrainStep:
     where every such reduction is one of our own kernels; tests/test_gpu_graph.py compares replay against eager."""
 
     def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3, augment=True,
-                 inject_mask_noise=False):
+                 inject_mask_noise=False, grad_sync=None):
         """inject_mask_noise=True: the (B,L) ranking noise of generate_mask becomes a static input filled by the caller
-        (deterministic replays for the tests); otherwise it is drawn inside the graph."""
+        (deterministic replays for the tests); otherwise it is drawn inside the graph.
+        grad_sync: data-parallel mode -- TWO graphs (forward+backward | clip+AdamW+EMA) with the bucketed RCCL
+        all-reduce of the flat gradient buffers issued eagerly between them."""
         self.static_in = example.clone()
         L = (model.module if hasattr(model, "module") else model).num_group
         self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
         self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
-        kw = dict(augment=augment, mask_noise=self.static_noise)
+        self.grad_sync = grad_sync
+        kw = dict(augment=augment, mask_noise=self.static_noise, grad_sync=grad_sync)
+        if grad_sync is not None:
+            grad_sync.overlap = False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -306,14 +333,25 @@ class GraphedPretrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args, **kw)
+        if grad_sync is None:
+            self.graph2 = None
+            with torch.cuda.graph(self.graph):
+                self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args, **kw)
+        else:
+            with torch.cuda.graph(self.graph):
+                self.out = step_forward_backward(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+                self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 
     def __call__(self, samples, mask_noise=None):
         self.static_in.copy_(samples, non_blocking=True)
         if self.static_noise is not None:
             self.static_noise.copy_(mask_noise, non_blocking=True)
         self.graph.replay()
+        if self.graph2 is not None:
+            self.grad_sync.finish()
+            self.graph2.replay()
         return self.out
 
 

@@ -41,6 +41,7 @@ def test_graph_replay_equals_eager(bf16):
     g = E.GraphedPretrainStep.__new__(E.GraphedPretrainStep)
     g.static_in = pool[0].clone()
     g.static_noise = noise[0].clone()
+    g.graph2 = g.grad_sync = None
     for i in range(3):
         E.pretrain_step(m, ema, opt, pool[i % 3].clone(), 200, args, mask_noise=noise[i], augment=False)
     torch.cuda.synchronize()
@@ -56,3 +57,55 @@ def test_graph_replay_equals_eager(bf16):
     for a, b in zip(got, eager[3:]):
         for x, y in zip(a, b):
             assert x == x and abs(x - y) <= tol * abs(y), (got, eager[3:])
+
+
+def test_two_graph_data_parallel_path_on_one_gpu():
+    """The data-parallel capture (forward+backward graph | eager all-reduce of the flat buckets | update graph) with a
+    world of one: gradients accumulate into GradSync's flat views inside the first graph; results must equal eager."""
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import models_mae_learn_loss as M
+    from tests import clouds
+    B = 8
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0,
+                           warmup_epochs=40)
+    pool = [clouds.uniform(B, 1024, 70 + i).cuda() for i in range(3)]
+    noise = [torch.rand(B, 64, generator=torch.Generator().manual_seed(i)).cuda() for i in range(8)]
+    res = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+        for mod in m.modules():
+            if isinstance(mod, M.DropPath):
+                mod.drop_prob = 0.0
+        ema = E.ModelEma(m, 0.999)
+        opt = E.build_optimizer(m, lr=2e-4, capturable=True)
+        sync = E.GradSync(m.parameters(), bucket_bytes=32 << 20)
+        assert len(sync.buckets) == 5
+        hist = []
+        if mode == "eager":
+            for i in range(8):
+                o = E.pretrain_step(m, ema, opt, pool[i % 3].clone(), 200, args, grad_sync=sync, mask_noise=noise[i], augment=False)
+                hist.append([float(o["loss_chfr"]), float(o["grad_norm"])])
+        else:
+            g = E.GraphedPretrainStep.__new__(E.GraphedPretrainStep)
+            g.static_in, g.static_noise, g.grad_sync = pool[0].clone(), noise[0].clone(), sync
+            sync.overlap = False
+            for i in range(3):
+                o = E.pretrain_step(m, ema, opt, pool[i % 3].clone(), 200, args, grad_sync=sync, mask_noise=noise[i], augment=False)
+                hist.append([float(o["loss_chfr"]), float(o["grad_norm"])])
+            torch.cuda.synchronize()
+            g.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.graph):
+                g.out = E.step_forward_backward(m, ema, g.static_in, 200, args, grad_sync=sync, mask_noise=g.static_noise,
+                                                augment=False, optimizer=opt)
+            g.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g.graph2, pool=g.graph.pool()):
+                g.out["grad_norm"] = E.step_update(m, ema, opt)
+            for i in range(3, 8):
+                o = g(pool[i % 3], noise[i])
+                torch.cuda.synchronize()
+                hist.append([float(o["loss_chfr"]), float(o["grad_norm"])])
+        res[mode] = hist
+    for a, b in zip(res["graph"], res["eager"]):
+        for x, y in zip(a, b):
+            assert x == x and abs(x - y) <= 2e-2 * abs(y), res
