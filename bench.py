@@ -122,6 +122,7 @@ def main():
     from gm3d_amd import models_mae_learn_loss as M
     from gm3d_amd import ops
 
+    tuned = False if os.environ.get("PYTORCH_TUNABLEOP_TUNING") == "1" else E.enable_tuned_gemms()
     torch.manual_seed(0)                      # identical random-init weights on every rank
     model = M.mae_vit_base_patch16_dec512d8b(norm_pix_loss=False).to(device).train()
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
@@ -230,6 +231,7 @@ def main():
                          "avg_launch_us": tsum["avg_ms"] * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
             "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph else "eager",
+            "tuned_gemm_table": bool(tuned),
             "hip_kernels_ms_per_step": per_step,
             "loss": loss,
         }

@@ -20,6 +20,29 @@ from contextlib import nullcontext
 import torch
 import torch.distributed as dist
 
+# --------------------------------------------------------------------------- GEMM selection
+def enable_tuned_gemms(tune_missing=False):
+    """Point PyTorch's TunableOp at the hipBLASLt solution choices recorded for this step's GEMM shapes on gfx950
+    (gm3d_amd/tuning/tunableop_gfx950_b128.csv, produced by running bench.py with PYTORCH_TUNABLEOP_TUNING=1).
+    The step's GEMMs are small (M = 3200..8192 rows, K,N = 384..1536) or tall (262,144 rows): hipBLASLt's default
+    heuristic leaves ~5 % of the step on the table for them.  Results recorded for another hipBLASLt/PyTorch
+    version are ignored by TunableOp's validators; with tune_missing=True unknown shapes are tuned on first use."""
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "tunableop_gfx950_b128.csv")
+    try:
+        import torch.cuda.tunable as tunable
+        tunable.enable(True)
+        tunable.tuning_enable(bool(tune_missing))
+        ok = bool(tunable.read_file(path)) if os.path.exists(path) else False
+        try:
+            tunable.write_file_on_exit(False)     # never write into the working directory
+        except Exception:
+            pass
+        return ok
+    except Exception:   # TunableOp is an optimisation, never a requirement
+        return False
+
+
 # --------------------------------------------------------------------------- augmentation
 class PointcloudScaleAndTranslate(object):
     """P/datasets/data_transforms.py:20-35, vectorised: one (B,3) scale ~ U[lo,hi] and one (B,3) shift ~
