@@ -31,6 +31,7 @@ SIGNATURES = {
     "gm3d_residual_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_ln_partial_rows": [_i],
     "gm3d_colsum_finish": [_vp, _i, _i, _i, _vp, _i, _vp],
+    "gm3d_colsum_finish_batched": [_vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _i, _vp],
     "gm3d_bias_gelu_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_bias_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_gelu_partial_rows": [_i],

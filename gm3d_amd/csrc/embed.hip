@@ -20,33 +20,6 @@
 
 namespace gm3d {
 
-typedef __bf16 bf16_t;
-
-template <class T> struct V8;
-template <> struct V8<float> {
-    static __device__ __forceinline__ void load(const float* p, float* v) {
-        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    }
-    static __device__ __forceinline__ void store(float* p, const float* v) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
-};
-template <> struct V8<bf16_t> {
-    typedef __bf16 v8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
-        const v8 a = *reinterpret_cast<const v8*>(p);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
-    }
-    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
-        v8 a;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
-        *reinterpret_cast<v8*>(p) = a;
-    }
-};
 
 // Thread layout shared by the (G, K, C) kernels: a workgroup is SL row-slices x TPR threads per row, each
 // thread owning 8 consecutive channels (16 B in bf16).  C in {128, 256, 384, 512}; blockDim = SL * TPR.

@@ -17,7 +17,6 @@
 
 namespace gm3d {
 
-typedef __bf16 bf16_t;
 constexpr int LNC = 384;            // model width (trans_dim, models_mae_learn_loss.py:110)
 constexpr int LN_PER_LANE = 6;      // 3 pairs per lane: columns 2*lane + 128*i + {0,1}
 
@@ -226,18 +225,16 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(t % cpr) * 8;
         const size_t o = (t / cpr) * (size_t)C + c;
+        float v[8];
+        V8<T>::load(f + o, v);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float a, b;
-            Pair<T>::load(f + o + 2 * i, a, b);
-            a += bias[c + 2 * i]; b += bias[c + 2 * i + 1];
-            Pair<T>::store(g + o + 2 * i, gelu_f(a), gelu_f(b));
-        }
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i] + bias[c + i]);
+        V8<T>::store(g + o, v);
     }
 }
 
 // df = dg * GELU'(f + bias); partial[blockIdx][c] = sum over this block's rows of df (bias gradient).
-// blockDim = C/8 threads: thread t owns columns 8t..8t+7 for every row the block visits.
+// blockDim = C/8 threads: thread t owns columns 8t..8t+7 for every row the block visits (two rows in flight).
 template <class T>
 __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ f, const float* __restrict__ bias,
                                      T* __restrict__ df, float* __restrict__ partial, int R, int C) {
@@ -245,24 +242,57 @@ __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restri
     float bv[8], s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { bv[i] = bias[c + i]; s[i] = 0.f; }
-    for (int r = blockIdx.x; r < R; r += gridDim.x) {
-        const size_t o = (size_t)r * C + c;
+    int r = blockIdx.x;
+    for (; r + (int)gridDim.x < R; r += 2 * gridDim.x) {
+        const size_t o0 = (size_t)r * C + c, o1 = (size_t)(r + gridDim.x) * C + c;
+        float f0[8], g0[8], f1[8], g1[8];
+        V8<T>::load(f + o0, f0); V8<T>::load(dg + o0, g0);
+        V8<T>::load(f + o1, f1); V8<T>::load(dg + o1, g1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float fa, fb, ga, gb;
-            Pair<T>::load(f + o + 2 * i, fa, fb);
-            Pair<T>::load(dg + o + 2 * i, ga, gb);
-            const float da = ga * gelu_grad_f(fa + bv[2 * i]), db = gb * gelu_grad_f(fb + bv[2 * i + 1]);
-            Pair<T>::store(df + o + 2 * i, da, db);
-            s[2 * i] += da; s[2 * i + 1] += db;
+        for (int i = 0; i < 8; ++i) {
+            g0[i] *= gelu_grad_f(f0[i] + bv[i]); g1[i] *= gelu_grad_f(f1[i] + bv[i]);
+            s[i] += g0[i] + g1[i];
         }
+        V8<T>::store(df + o0, g0); V8<T>::store(df + o1, g1);
+    }
+    for (; r < R; r += gridDim.x) {
+        const size_t o0 = (size_t)r * C + c;
+        float f0[8], g0[8];
+        V8<T>::load(f + o0, f0); V8<T>::load(dg + o0, g0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { g0[i] *= gelu_grad_f(f0[i] + bv[i]); s[i] += g0[i]; }
+        V8<T>::store(df + o0, g0);
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i) partial[(size_t)blockIdx.x * C + c + i] = s[i];
 }
 
+// Batched second stage: job j sums partial[j*job_stride + r*pitch + c] over r < nrows into out[j*out_stride + c].
+__global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const float* __restrict__ partial, size_t job_stride,
+                                                                    int nrows, int pitch, int ncols,
+                                                                    float* __restrict__ out, int out_stride) {
+    __shared__ float red[8][32];
+    const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const float* p = partial + (size_t)blockIdx.y * job_stride;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < ncols) {
+        int r = slice;
+        for (; r + 8 < nrows; r += 16) { s0 += p[(size_t)r * pitch + c]; s1 += p[(size_t)(r + 8) * pitch + c]; }
+        for (; r < nrows; r += 8) s0 += p[(size_t)r * pitch + c];
+    }
+    red[slice][cx] = s0 + s1;
+    __syncthreads();
+    if (slice == 0 && c < ncols) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) s += red[k][cx];
+        out[(size_t)blockIdx.y * out_stride + c] = s;
+    }
+}
+
 static inline int ln_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 512 ? 512 : g); }
-static inline int gelu_bwd_grid(int R) { return R < 256 ? R : 256; }
+static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
 
 }  // namespace gm3d
 
@@ -353,6 +383,18 @@ extern "C" int gm3d_bias_gelu_bwd(const void* dg, const void* f, const float* bi
     else
         hipLaunchKernelGGL(bias_gelu_bwd_kernel<float>, dim3(gelu_bwd_grid(R)), dim3(C / 8), 0, st, (const float*)dg,
                            (const float*)f, bias, (float*)df, partial, R, C);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_colsum_finish_batched(const float* partial, int njobs, long long job_stride, int nrows, int pitch,
+                                          int ncols, float* out, int out_stride, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!partial || !out || njobs < 1 || nrows < 0 || ncols < 1 || pitch < ncols || job_stride < 0 || out_stride < ncols)
+        return GM3D_EINVAL;
+    if (njobs > 65535) return GM3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(colsum_finish_batched_kernel, dim3((ncols + 31) / 32, njobs), dim3(256), 0, (hipStream_t)stream, partial,
+                       (size_t)job_stride, nrows, pitch, ncols, out, out_stride);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

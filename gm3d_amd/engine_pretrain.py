@@ -137,8 +137,7 @@ class ModelEma:
         if self._pairs is None:
             self._build(model)
         fe, fm, ie, im = self._pairs
-        torch._foreach_mul_(fe, self.decay)
-        torch._foreach_add_(fe, fm, alpha=1.0 - self.decay)
+        torch._foreach_lerp_(fe, fm, 1.0 - self.decay)      # v + (1-decay)*(m - v): one multi-tensor pass
         for e, m in zip(ie, im):
             e.copy_((e * self.decay + (1.0 - self.decay) * m).to(e.dtype))
 

@@ -99,17 +99,22 @@ def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, e
     return out_res, h, mean, rstd
 
 
-def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R, dy=None):
-    """-> dx (R,C) f32, dy (R,C) adt | None, sums (3,C) f32 = [dgamma, dbeta, colsum(dy)]."""
+def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R, dy=None, partial=None):
+    """-> dx (R,C) f32, dy (R,C) adt | None, sums (3,C) f32 = [dgamma, dbeta, colsum(dy)].
+    With `partial` given (a (rows, 3C) slice of a batched buffer) the second stage is left to the caller."""
     dev = gamma.device
     dx = torch.empty(R, LNC, dtype=torch.float32, device=dev)
     if dy is None and want_dy:
         dy = torch.empty(R, LNC, dtype=adt, device=dev)
     nrows = lib.gm3d_ln_partial_rows(R)
-    partial = torch.empty(nrows, 3 * LNC, dtype=torch.float32, device=dev)
+    defer = partial is not None
+    if partial is None:
+        partial = torch.empty(nrows, 3 * LNC, dtype=torch.float32, device=dev)
     _launch("gm3d_residual_ln_bwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_bwd, _ptr(dh), _ptr(gin), _ptr(x),
             _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rowscale), int(rows_per_sample), _ptr(dx), _ptr(dy), _ptr(acc),
             _ptr(partial), R, LNC, _DT[adt], _stream())
+    if defer:
+        return dx, dy, None
     sums = torch.empty(3, LNC, dtype=torch.float32, device=dev)
     _launch("gm3d_colsum_finish", {"rows": nrows, "cols": 3 * LNC}, lib.gm3d_colsum_finish, _ptr(partial), nrows, 3 * LNC,
             3 * LNC, _ptr(sums), 0, _stream())
@@ -125,19 +130,31 @@ def bias_gelu_fwd(f, bias, adt, g=None):
     return g
 
 
-def bias_gelu_bwd(dg, f, bias, adt, df=None):
-    """-> df (R,C) adt, dbias (C) f32."""
+def bias_gelu_bwd(dg, f, bias, adt, df=None, partial=None):
+    """-> df (R,C) adt, dbias (C) f32 (None when `partial`, a slice of a batched buffer, is given)."""
     R, C = f.shape
     if df is None:
         df = torch.empty_like(f)
     nrows = lib.gm3d_gelu_partial_rows(R)
-    partial = torch.empty(nrows, C, dtype=torch.float32, device=f.device)
+    defer = partial is not None
+    if partial is None:
+        partial = torch.empty(nrows, C, dtype=torch.float32, device=f.device)
     _launch("gm3d_bias_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_bias_gelu_bwd, _ptr(dg), _ptr(f), _ptr(bias),
             _ptr(df), _ptr(partial), R, C, _DT[adt], _stream())
+    if defer:
+        return df, None
     db = torch.empty(C, dtype=torch.float32, device=f.device)
     _launch("gm3d_colsum_finish", {"rows": nrows, "cols": C}, lib.gm3d_colsum_finish, _ptr(partial), nrows, C, C, _ptr(db), 0,
             _stream())
     return df, db
+
+
+def finish_batched(partial, out):
+    """partial (J, rows, cols) f32 -> out (J, cols): every job's second stage in one launch."""
+    J, rows, cols = partial.shape
+    _launch("gm3d_colsum_finish_batched", {"rows": J * rows, "cols": cols}, lib.gm3d_colsum_finish_batched, _ptr(partial), J,
+            rows * cols, rows, cols, cols, _ptr(out), cols, _stream())
+    return out
 
 
 def _attention_fwd(qkv, B, T, H, scale, out=None):
@@ -249,9 +266,16 @@ class TransformerStackFn(torch.autograd.Function):
         DF = torch.empty(nblk, R, 4 * C, dtype=adt, device=dev)
         DP = torch.empty(nblk, R, C, dtype=adt, device=dev)
         DQ = torch.empty(nblk, R, 3 * C, dtype=adt, device=dev)
+        # column-sum partials of every LayerNorm site (job 2i: LN1 of block i, 2i+1: LN2, 2*nblk: final) and of every
+        # GELU site, finished by ONE launch each after the loop
+        PLN = torch.empty(2 * nblk + 1, lib.gm3d_ln_partial_rows(R), 3 * C, dtype=torch.float32, device=dev)
+        SLN = torch.empty(2 * nblk + 1, 3, C, dtype=torch.float32, device=dev)
+        PGL = torch.empty(nblk, lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32, device=dev)
+        SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
         dp2_last = meta["dp"][nblk - 1][1]
-        G, d_o, sums = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1])
-        g_final_w, g_final_b, db2 = sums[0], sums[1], sums[2]
+        G, d_o, _ = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1],
+                                    partial=PLN[2 * nblk])
+        g_final_w, g_final_b, db2 = SLN[2 * nblk, 0], SLN[2 * nblk, 1], SLN[2 * nblk, 2]
         dpos = torch.zeros(R, C, dtype=torch.float32, device=dev)
         for i in range(nblk - 1, -1, -1):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
@@ -262,19 +286,23 @@ class TransformerStackFn(torch.autograd.Function):
             # mlp branch: x2 = x1 + dp2 * (g @ W2^T + b2)
             gi[10] = db2
             dg = d_o @ weight_cache.get(w2, adt)
-            df, gi[8] = bias_gelu_bwd(dg, f, b1, adt, df=DF[i])
+            df, _ = bias_gelu_bwd(dg, f, b1, adt, df=DF[i], partial=PGL[i])
+            gi[8] = SGL[i]
             dh2 = df @ weight_cache.get(w1, adt)
-            dx1, d_p, s2 = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R, dy=DP[i])
-            gi[5], gi[6], gi[4] = s2[0], s2[1], s2[2]
+            dx1, d_p, _ = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R, dy=DP[i],
+                                          partial=PLN[2 * i + 1])
+            gi[5], gi[6], gi[4] = SLN[2 * i + 1, 0], SLN[2 * i + 1, 1], SLN[2 * i + 1, 2]
             # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
             da = d_p @ weight_cache.get(wproj, adt)
             dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
             dh1 = dqkv @ weight_cache.get(wqkv, adt)
-            G, d_o, s1 = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
-                                         dy=DO[i - 1] if i > 0 else None)
-            gi[0], gi[1] = s1[0], s1[1]
-            db2 = s1[2]
+            G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
+                                        dy=DO[i - 1] if i > 0 else None, partial=PLN[2 * i])
+            gi[0], gi[1] = SLN[2 * i, 0], SLN[2 * i, 1]
+            db2 = SLN[2 * i, 2]
             grads[i * PER_BLOCK:(i + 1) * PER_BLOCK] = gi
+        finish_batched(PLN, SLN.view(2 * nblk + 1, 3 * C))
+        finish_batched(PGL, SGL)
         # all weight gradients of the stack: 4 batched GEMMs
         gw2, gw1 = _wgrad_batched(DO, GG), _wgrad_batched(DF, H2)
         gwp, gwq = _wgrad_batched(DP, A), _wgrad_batched(DQ, H1)
@@ -292,10 +320,12 @@ def run_stack(blocks, final_norm, x, pos, training):
     adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
         or x.dtype == torch.bfloat16 else torch.float32
     B = x.shape[0]
-    dp = []
+    probs = []
     for b in blocks:
         p = getattr(b.drop_path, "drop_prob", 0.0)
-        dp.append((M.drop_path_scale(B, p, training, x.device), M.drop_path_scale(B, p, training, x.device)))
+        probs += [p, p]
+    scales = M.drop_path_scales(B, probs, training, x.device)
+    dp = [(scales[2 * i], scales[2 * i + 1]) for i in range(len(blocks))]
     meta = {"num_heads": blocks[0].attn.num_heads, "scale": blocks[0].attn.scale, "eps": blocks[0].norm1.eps,
             "final_eps": final_norm.eps, "adt": adt, "dp": dp, "grad": torch.is_grad_enabled()}
     params = []

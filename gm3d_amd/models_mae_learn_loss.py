@@ -44,6 +44,24 @@ def drop_path_scale(B, p, training, device):
     return (keep + torch.rand(B, dtype=torch.float32, device=device)).floor_().div_(keep)
 
 
+_default_drop_path_scale = drop_path_scale
+
+
+def drop_path_scales(B, probs, training, device):
+    """DropPath factors for a whole stack (two per block): one uniform draw of shape (n_active, B) instead of one per
+    site.  Falls back to per-site calls when drop_path_scale has been replaced (the tests replay recorded draws)."""
+    if drop_path_scale is not _default_drop_path_scale:
+        return [drop_path_scale(B, p, training, device) for p in probs]
+    active = [i for i, p in enumerate(probs) if p > 0.0 and training]
+    out = [None] * len(probs)
+    if active:
+        u = torch.rand(len(active), B, dtype=torch.float32, device=device)
+        for j, i in enumerate(active):
+            k = 1.0 - probs[i]
+            out[i] = (u[j] + k).floor_().div_(k)
+    return out
+
+
 FUSED_STACK = True   # False: per-op PyTorch modules below (kept as the in-package cross-check of the fused path)
 FUSED_EMBED = True   # same switch for the mini-PointNet token embed (gm3d_amd/embed.py)
 FUSED_HEADS = True   # ... and for pos_embed, the two heads, the mask-token expand and the ranking loss (gm3d_amd/heads.py)

@@ -138,6 +138,10 @@ int gm3d_ln_partial_rows(int R);   /* rows of `partial` the call above writes */
 int gm3d_colsum_finish(const float *partial, int nrows, int pitch, int ncols, float *out, int accumulate,
                        gm3d_stream_t stream);
 
+/* Batched form: job j sums partial[j*job_stride + r*pitch + c] over r < nrows into out[j*out_stride + c]. */
+int gm3d_colsum_finish_batched(const float *partial, int njobs, long long job_stride, int nrows, int pitch, int ncols,
+                               float *out, int out_stride, gm3d_stream_t stream);
+
 /* g = GELU(f + bias), exact erf form (nn.GELU, Mlp at models/Point_MAE.py:82-98).  C % 8 == 0. */
 int gm3d_bias_gelu_fwd(const void *f, const float *bias, void *g, int R, int C, int dtype,
                        gm3d_stream_t stream);
