@@ -156,9 +156,22 @@ def main():
     psum = probe.summary()
     dominant = max((n for n in psum if algorithmic(n, psum[n]["meta"])), key=lambda n: psum[n]["total_ms"])
 
+    graph_note = None
     if use_graph:
-        graphed = E.GraphedPretrainStep(model, model_ema, optimizer, step_args, pool[0], args.epoch, grad_sync=grad_sync)
-
+        try:
+            graphed = E.GraphedPretrainStep(model, model_ema, optimizer, step_args, pool[0], args.epoch, grad_sync=grad_sync)
+        except Exception as ex:  # never lose the measurement to a capture problem: fall back to eager launches
+            graph_note = "capture failed (%s: %s); eager" % (type(ex).__name__, str(ex)[:120])
+            use_graph = False
+            if grad_sync is not None:
+                grad_sync.overlap = True
+    if world > 1:                 # every rank must take the same path
+        flag = torch.tensor([1.0 if use_graph else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if use_graph and float(flag) == 0.0:
+            use_graph, graph_note = False, "another rank failed to capture; eager"
+            grad_sync.overlap = True
+    if use_graph:
         def step(i):
             E.adjust_learning_rate(optimizer, args.epoch + i / 1000.0, step_args)
             return graphed(pool[i % len(pool)])
@@ -168,6 +181,8 @@ def main():
     else:
         step = eager_step
         timer = ops.KernelTimer(only=[dominant])
+        for i in range(args.warmup if graph_note else 0):
+            out = step(i)
 
     fence()
     ops.set_kernel_timer(timer)
@@ -230,7 +245,8 @@ def main():
                          "frac": achieved / peak, "traffic": None,
                          "avg_launch_us": tsum["avg_ms"] * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
-            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph else "eager",
+            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph
+            else (graph_note or "eager"),
             "tuned_gemm_table": bool(tuned),
             "hip_kernels_ms_per_step": per_step,
             "loss": loss,

@@ -355,15 +355,18 @@ class GraphedPretrainStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        # with a process group alive its watchdog thread polls events; only the capturing thread's calls may abort a capture
+        import os
+        mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
         if grad_sync is None:
             self.graph2 = None
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args, **kw)
         else:
-            with torch.cuda.graph(self.graph):
+            with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = step_forward_backward(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
             self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 
     def __call__(self, samples, mask_noise=None):
