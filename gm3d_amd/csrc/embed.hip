@@ -83,7 +83,22 @@ __global__ void group_max_fwd_kernel(const T* __restrict__ in, const float* __re
         int bk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bk[i] = 0; }
-        for (int k = sl; k < K; k += SL) {
+        int k = sl;
+        for (; k + 3 * SL < K; k += 4 * SL) {   // four rows in flight per thread: the pass is latency-, not bandwidth-limited otherwise
+            float v0[8], v1[8], v2[8], v3[8];
+            V8<T>::load(in + ((size_t)g * K + k) * C + c, v0);
+            V8<T>::load(in + ((size_t)g * K + k + SL) * C + c, v1);
+            V8<T>::load(in + ((size_t)g * K + k + 2 * SL) * C + c, v2);
+            V8<T>::load(in + ((size_t)g * K + k + 3 * SL) * C + c, v3);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                if (v0[i] > best[i]) { best[i] = v0[i]; bk[i] = k; }
+                if (v1[i] > best[i]) { best[i] = v1[i]; bk[i] = k + SL; }
+                if (v2[i] > best[i]) { best[i] = v2[i]; bk[i] = k + 2 * SL; }
+                if (v3[i] > best[i]) { best[i] = v3[i]; bk[i] = k + 3 * SL; }
+            }
+        }
+        for (; k < K; k += SL) {
             float v[8];
             V8<T>::load(in + ((size_t)g * K + k) * C + c, v);
 #pragma unroll

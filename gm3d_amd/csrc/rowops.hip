@@ -211,9 +211,21 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     }
 }
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
+// erf for the bf16 path: Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's 4e-3 resolution) costs one
+// rcp + one exp + 5 FMAs, about half of libm's erff; the GELU passes are VALU-bound on it (12.6 M elements per call).
+// The f32 (parity) path keeps libm's erff.
+template <class T> __device__ __forceinline__ float erf_t(float x);
+template <> __device__ __forceinline__ float erf_t<float>(float x) { return erff(x); }
+template <> __device__ __forceinline__ float erf_t<bf16_t>(float x) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float r = 1.0f - poly * __expf(-ax * ax);
+    return copysignf(r, x);
+}
+template <class T> __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_t<T>(x * 0.70710678118654752440f)); }
+template <class T> __device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erf_t<T>(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
 // g = GELU(f + bias), exact erf form (nn.GELU default).  C % 8 == 0; one thread = 8 consecutive columns.
@@ -228,7 +240,7 @@ __global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict_
         float v[8];
         V8<T>::load(f + o, v);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_f(v[i] + bias[c + i]);
+        for (int i = 0; i < 8; ++i) v[i] = gelu_f<T>(v[i] + bias[c + i]);
         V8<T>::store(g + o, v);
     }
 }
@@ -250,7 +262,7 @@ __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restri
         V8<T>::load(f + o1, f1); V8<T>::load(dg + o1, g1);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            g0[i] *= gelu_grad_f(f0[i] + bv[i]); g1[i] *= gelu_grad_f(f1[i] + bv[i]);
+            g0[i] *= gelu_grad_f<T>(f0[i] + bv[i]); g1[i] *= gelu_grad_f<T>(f1[i] + bv[i]);
             s[i] += g0[i] + g1[i];
         }
         V8<T>::store(df + o0, g0); V8<T>::store(df + o1, g1);
@@ -260,7 +272,7 @@ __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restri
         float f0[8], g0[8];
         V8<T>::load(f + o0, f0); V8<T>::load(dg + o0, g0);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { g0[i] *= gelu_grad_f(f0[i] + bv[i]); s[i] += g0[i]; }
+        for (int i = 0; i < 8; ++i) { g0[i] *= gelu_grad_f<T>(f0[i] + bv[i]); s[i] += g0[i]; }
         V8<T>::store(df + o0, g0);
     }
 #pragma unroll
@@ -292,6 +304,7 @@ __global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const float*
 }
 
 static inline int ln_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 512 ? 512 : g); }
+static inline int ln_fwd_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per wave
 static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
 
 }  // namespace gm3d
@@ -311,10 +324,10 @@ extern "C" int gm3d_residual_ln_fwd(const float* res, const void* y, const float
     if (R == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GM3D_BF16)
-        hipLaunchKernelGGL(residual_ln_fwd_kernel<bf16_t>, dim3(ln_grid(R)), dim3(256), 0, st, res, (const bf16_t*)y, bias,
+        hipLaunchKernelGGL(residual_ln_fwd_kernel<bf16_t>, dim3(ln_fwd_grid(R)), dim3(256), 0, st, res, (const bf16_t*)y, bias,
                            rowscale, rows_per_sample, (const bf16_t*)add, gamma, beta, eps, out_res, (bf16_t*)h, mean, rstd, R);
     else
-        hipLaunchKernelGGL(residual_ln_fwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, res, (const float*)y, bias,
+        hipLaunchKernelGGL(residual_ln_fwd_kernel<float>, dim3(ln_fwd_grid(R)), dim3(256), 0, st, res, (const float*)y, bias,
                            rowscale, rows_per_sample, (const float*)add, gamma, beta, eps, out_res, (float*)h, mean, rstd, R);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;

@@ -55,11 +55,18 @@ def drop_path_scales(B, probs, training, device):
     active = [i for i, p in enumerate(probs) if p > 0.0 and training]
     out = [None] * len(probs)
     if active:
-        u = torch.rand(len(active), B, dtype=torch.float32, device=device)
+        key = (tuple(probs[i] for i in active), str(device))
+        keep = _keep_cache.get(key)
+        if keep is None:   # built once (outside any stream capture: the eager warm-up steps come first)
+            keep = torch.tensor([1.0 - p for p in key[0]], dtype=torch.float32).unsqueeze(1).to(device)
+            _keep_cache[key] = keep
+        s = (torch.rand(len(active), B, dtype=torch.float32, device=device) + keep).floor_().div_(keep)   # 3 launches in all
         for j, i in enumerate(active):
-            k = 1.0 - probs[i]
-            out[i] = (u[j] + k).floor_().div_(k)
+            out[i] = s[j]
     return out
+
+
+_keep_cache = {}
 
 
 FUSED_STACK = True   # False: per-op PyTorch modules below (kept as the in-package cross-check of the fused path)
