@@ -127,8 +127,8 @@ def main():
     model = M.mae_vit_base_patch16_dec512d8b(norm_pix_loss=False).to(device).train()
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
     use_graph = not args.no_graph
-    optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, capturable=use_graph)
-    grad_sync = E.GradSync(model.parameters(), bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=model_ema)
+    grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=args.bucket_mb << 20) if world > 1 else None
     step_args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=not args.fp32, accum_iter=1,
                                 lr=1e-3, min_lr=0.0, warmup_epochs=40)
     torch.manual_seed(1234 + rank)            # per-rank augmentation / mask / DropPath streams

@@ -23,6 +23,7 @@ SOURCES = {
     "attention.hip": [],
     "rowops.hip": [],
     "embed.hip": [],
+    "optim.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

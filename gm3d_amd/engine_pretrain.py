@@ -96,7 +96,14 @@ def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
-def build_optimizer(model, lr=1e-3, weight_decay=0.05, fused=True, capturable=False):
+def build_optimizer(model, lr=1e-3, weight_decay=0.05, fused=True, capturable=False, flat=False, model_ema=None,
+                    clip_grad=5.0):
+    """flat=True: FlatAdamWEma (gm3d_amd/optim.py) -- clip + AdamW + EMA + bf16 shadows in one pass over flat buffers;
+    pass the ModelEma so the teacher's parameters join the layout.  Otherwise torch.optim.AdamW with the reference's
+    parameter groups."""
+    if flat:
+        from .optim import FlatAdamWEma
+        return FlatAdamWEma(model, model_ema, lr=lr, weight_decay=weight_decay, max_norm=clip_grad)
     groups = add_weight_decay(model, weight_decay=weight_decay)
     kw = {}
     if fused and next(model.parameters()).is_cuda:
@@ -126,7 +133,10 @@ class ModelEma:
         msd = model.state_dict()
         needs_module = any(k.startswith("module.") for k in msd)
         fe, fm, ie, im = [], [], [], []
+        skip = set(k for k, _ in self.ema.named_parameters()) if getattr(self, "params_in_optimizer", False) else ()
         for k, v in self.ema.state_dict().items():
+            if k in skip:   # FlatAdamWEma updates the teacher's parameters inside its own kernel; buffers stay here
+                continue
             mv = msd["module." + k if needs_module else k]
             (fe if v.dtype.is_floating_point else ie).append(v)
             (fm if v.dtype.is_floating_point else im).append(mv)
@@ -137,7 +147,8 @@ class ModelEma:
         if self._pairs is None:
             self._build(model)
         fe, fm, ie, im = self._pairs
-        torch._foreach_lerp_(fe, fm, 1.0 - self.decay)      # v + (1-decay)*(m - v): one multi-tensor pass
+        if fe:
+            torch._foreach_lerp_(fe, fm, 1.0 - self.decay)  # v + (1-decay)*(m - v): one multi-tensor pass
         for e, m in zip(ie, im):
             e.copy_((e * self.decay + (1.0 - self.decay) * m).to(e.dtype))
 
@@ -183,6 +194,36 @@ class GradSync:
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
 
+    @classmethod
+    def from_flat(cls, optimizer, bucket_bytes=32 << 20, process_group=None):
+        """Buckets = contiguous chunks of FlatAdamWEma's gradient buffer (its layout, not backward order): gradients are
+        produced, all-reduced and consumed in place -- no flatten/unflatten copies."""
+        self = cls.__new__(cls)
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        pairs = optimizer.flat_grad_views()
+        self.params = [p for p, _ in pairs]
+        self._views = pairs
+        G = optimizer.G
+        chunk = max(bucket_bytes // 4, 1)
+        self.buckets, self._owner = [], {}
+        bounds = list(range(0, G.numel(), chunk)) + [G.numel()]
+        for b, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+            self.buckets.append((G[lo:hi], []))
+        for p, off in zip(optimizer._params, optimizer._offs):
+            last = min((off + p.numel() - 1) // chunk, len(self.buckets) - 1)     # complete when its LAST element's chunk is
+            self.buckets[last][1].append(p)
+            self._owner[p] = last
+        self._flat = G
+        self._pending = [len(ps) for _, ps in self.buckets]
+        self._works, self._launched = [], [False] * len(self.buckets)
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.overlap = False          # chunk completion does not follow backward order: issue everything in finish()
+        for p, g in pairs:
+            p.grad = g
+            p.register_post_accumulate_grad_hook(self._hook)
+        return self
+
     def _seal(self, ps):
         n = sum(p.numel() for p in ps)
         flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
@@ -194,8 +235,13 @@ class GradSync:
         self.buckets.append((flat, ps))
 
     def zero_grad(self):
-        for flat, _ in self.buckets:
-            flat.zero_()
+        if getattr(self, "_flat", None) is not None:
+            self._flat.zero_()
+            for p, g in self._views:
+                p.grad = g
+        else:
+            for flat, _ in self.buckets:
+                flat.zero_()
         self._pending = [len(ps) for _, ps in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -303,6 +349,10 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
 def step_update(model, model_ema, optimizer, clip_grad=5.0):
     """Second half (P/util/misc.py:262-266 + P/engine_pretrain.py:208-212): clip -> AdamW -> EMA."""
     raw = model.module if hasattr(model, "module") else model
+    if hasattr(optimizer, "flat_grad_views"):      # FlatAdamWEma: clip + AdamW + EMA(params) + bf16 shadows, one pass
+        grad_norm = optimizer.step()
+        model_ema.update(raw)                      # BatchNorm buffers only
+        return grad_norm
     grad_norm = torch.nn.utils.clip_grad_norm_(raw.parameters(), clip_grad, foreach=True)
     optimizer.step()
     model_ema.update(raw)

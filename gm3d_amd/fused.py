@@ -53,6 +53,10 @@ class _WeightCache:
         with torch.no_grad():
             torch._foreach_copy_(dst, self._groups[-1][0])
 
+    def pin_view(self, p, shadow):
+        """Register an externally maintained bf16 copy of `p` (FlatAdamWEma rewrites it inside its update kernel)."""
+        self._pinned[p.data_ptr()] = (shadow, weakref.ref(p))
+
     def _is_pinned(self, p):
         hit = self._pinned.get(p.data_ptr())
         return hit is not None and hit[1]() is p

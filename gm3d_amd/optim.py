@@ -1,0 +1,129 @@
+"""FlatAdamWEma: gradient clipping + AdamW + EMA teacher + bf16 GEMM shadows as ONE pass over flat buffers.
+
+Mirrors, with identical arithmetic, what the reference does in three places -- NativeScalerWithGradNormCount.__call__
+(P/util/misc.py:256-270: clip_grad_norm_(5.0) then optimizer.step()), the AdamW built by P/tools/builder.py:40-56 (no
+weight decay for 1-D / bias / token parameters) and timm ModelEma.update (P/engine_pretrain.py:212) -- but lays the state
+out for the machine: every parameter of the student is a view into one contiguous fp32 buffer (decayed parameters first),
+and so are its gradient slot, both Adam moments, the EMA teacher's parameters and the bf16 copies the GEMMs read.
+One step = gm3d_adamw_ema_flat_step (3 launches) instead of ~25 multi-tensor launches and ~9 passes over 147 MB.
+"""
+import ctypes
+
+import torch
+
+from ._capi import check, lib
+from .ops import _ptr, _stream
+
+
+def _split_decay(model):
+    decay, no_decay = [], []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        (no_decay if (len(p.shape) == 1 or name.endswith(".bias") or "token" in name) else decay).append((name, p))
+    return decay, no_decay
+
+
+class FlatAdamWEma(torch.optim.Optimizer):
+    def __init__(self, model, model_ema=None, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0):
+        decay, no_decay = _split_decay(model)
+        named = decay + no_decay
+        params = [p for _, p in named]
+        dev = params[0].device
+        if not params[0].is_cuda:
+            raise RuntimeError("FlatAdamWEma needs the model on the GPU (gm3d_amd has no CPU fallback)")
+        pad = lambda k: (k + 3) // 4 * 4
+        offs, off = [], 0
+        for i, p in enumerate(params):
+            if i == len(decay):
+                off = pad(off)
+                self.n_decay = off
+            offs.append(off)
+            off += p.numel()
+        if not no_decay:
+            self.n_decay = pad(off)
+        self.n = pad(off)
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.P, self.G = torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)
+        self.M, self.V = torch.zeros(self.n, **f32), torch.zeros(self.n, **f32)
+        self.PS = torch.zeros(self.n, dtype=torch.bfloat16, device=dev)
+        self.gviews = []
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.P[o:o + p.numel()].view_as(p)
+                view.copy_(p)
+                p.data = view
+                self.gviews.append(self.G[o:o + p.numel()].view_as(p))
+            self.PS.copy_(self.P)
+        self.ema = model_ema
+        self.E = self.ES = None
+        if model_ema is not None:
+            tparams = dict(model_ema.ema.named_parameters())
+            self.E = torch.zeros(self.n, **f32)
+            self.ES = torch.zeros(self.n, dtype=torch.bfloat16, device=dev)
+            with torch.no_grad():
+                for (name, p), o in zip(named, offs):
+                    t = tparams[name]
+                    view = self.E[o:o + p.numel()].view_as(t)
+                    view.copy_(t)
+                    t.data = view
+                self.ES.copy_(self.E)
+            model_ema.params_in_optimizer = True
+            model_ema._pairs = None
+        self.lr_dev = torch.tensor(float(lr), **f32)
+        self.step_dev = torch.zeros(1, **f32)
+        self.ema_w_dev = torch.zeros(1, **f32)
+        self.scal = torch.zeros(4, **f32)
+        self.partial = torch.zeros(max(lib.gm3d_flat_partial_rows(self.n), 1), **f32)
+        self.max_norm = float(max_norm)
+        defaults = dict(lr=self.lr_dev, weight_decay=weight_decay, betas=betas, eps=eps)
+        super().__init__([{"params": params}], defaults)
+        self.param_groups[0]["lr"] = self.lr_dev            # adjust_learning_rate fills this tensor in place
+        for p, o in zip(params, offs):                       # AdamW-shaped state (views) so state_dict() looks familiar
+            self.state[p] = {"step": self.step_dev, "exp_avg": self.M[o:o + p.numel()].view_as(p),
+                             "exp_avg_sq": self.V[o:o + p.numel()].view_as(p)}
+        self._params, self._offs, self._named = params, offs, named
+        self._register_shadows(model, model_ema)
+
+    def _register_shadows(self, model, model_ema):
+        """GEMM code asks weight_cache for the bf16 copy of a weight: hand it views of the flat shadows, which the
+        optimizer kernel rewrites every step (no separate cast launches)."""
+        from .fused import weight_cache
+        for p, o in zip(self._params, self._offs):
+            if p.dim() >= 2:
+                weight_cache.pin_view(p, self.PS[o:o + p.numel()].view_as(p))
+        if model_ema is not None:
+            tparams = dict(model_ema.ema.named_parameters())
+            for (name, p), o in zip(self._named, self._offs):
+                if p.dim() >= 2:
+                    weight_cache.pin_view(tparams[name], self.ES[o:o + p.numel()].view_as(p))
+
+    def flat_grad_views(self):
+        """The gradient slots: set `p.grad = view` to have backward accumulate straight into the flat buffer
+        (data-parallel runs all-reduce chunks of `self.G`)."""
+        return list(zip(self._params, self.gviews))
+
+    def zero_grad(self, set_to_none=True):
+        if set_to_none:
+            for p in self._params:
+                p.grad = None
+        else:
+            self.G.zero_()
+            for p, g in zip(self._params, self.gviews):
+                p.grad = g
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """-> gradient norm before clipping (device scalar)."""
+        if self._params[0].grad is not None and self._params[0].grad.data_ptr() != self.gviews[0].data_ptr():
+            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
+            torch._foreach_copy_(self.gviews, grads)
+        g = self.param_groups[0]
+        if self.ema is not None:
+            self.ema_w_dev.fill_(1.0 - float(self.ema.decay))
+        check(lib.gm3d_adamw_ema_flat_step(_ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS),
+                                           _ptr(self.ES), self.n, self.n_decay, _ptr(self.lr_dev), float(g["weight_decay"]),
+                                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), _ptr(self.ema_w_dev),
+                                           self.max_norm, _ptr(self.step_dev), _ptr(self.partial), _ptr(self.scal), _stream()),
+              "gm3d_adamw_ema_flat_step")
+        return self.scal[3]

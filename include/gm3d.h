@@ -220,6 +220,20 @@ int gm3d_lin3_gelu_bwd(const void *dout, const float *x, const float *w, const f
 int gm3d_rank_loss(const float *pred, const float *target, int B, int M, float *out, float *dpred,
                    gm3d_stream_t stream);
 
+/* ---- Optimizer step on flat buffers (gm3d_amd/csrc/optim.hip) ------------------------------------------------------
+ * clip_grad_norm_(max_norm) + torch.optim.AdamW + timm ModelEma.update + bf16 shadows, replacing
+ * NativeScalerWithGradNormCount.__call__ (Point-MAE_SA3D/util/misc.py:256-270), the AdamW of tools/builder.py:40-56 and
+ * model_ema.update (engine_pretrain.py:212).  All buffers hold n fp32 elements (n % 4 == 0) in one common layout whose
+ * first n_decay elements (n_decay % 4 == 0) take weight decay.  lr_dev, ema_w_dev (= 1 - decay) and step_dev (the step
+ * count, incremented here) are single floats in device memory.  ema / shadow_p / shadow_e (bf16) may be NULL.
+ * partial: gm3d_flat_partial_rows(n) floats of scratch; scal (4 floats) receives {clip coefficient, 1-beta1^t,
+ * 1-beta2^t, gradient norm before clipping}.  max_norm <= 0 disables clipping. */
+int gm3d_flat_partial_rows(long long n);
+int gm3d_adamw_ema_flat_step(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
+                             void *shadow_p, void *shadow_e, long long n, long long n_decay, const float *lr_dev,
+                             float weight_decay, float beta1, float beta2, float eps, const float *ema_w_dev,
+                             float max_norm, float *step_dev, float *partial, float *scal, gm3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,8 @@ def test_graph_replay_equals_eager(bf16):
             if isinstance(mod, M.DropPath):
                 mod.drop_prob = 0.0
         ema = E.ModelEma(m, 0.999)
-        opt = E.build_optimizer(m, lr=2e-4, capturable=True)
+        # bf16 case: the production configuration (FlatAdamWEma); fp32 case: torch.optim.AdamW (capturable)
+        opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema) if bf16 else E.build_optimizer(m, lr=2e-4, capturable=True)
         return m, ema, opt
 
     m, ema, opt = build()
@@ -78,8 +79,8 @@ def test_two_graph_data_parallel_path_on_one_gpu():
             if isinstance(mod, M.DropPath):
                 mod.drop_prob = 0.0
         ema = E.ModelEma(m, 0.999)
-        opt = E.build_optimizer(m, lr=2e-4, capturable=True)
-        sync = E.GradSync(m.parameters(), bucket_bytes=32 << 20)
+        opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema)
+        sync = E.GradSync.from_flat(opt, bucket_bytes=32 << 20)     # buckets = chunks of the optimizer's flat gradient buffer
         assert len(sync.buckets) == 5
         hist = []
         if mode == "eager":
