@@ -218,10 +218,7 @@ class GradSync:
         self._pending = [len(ps) for _, ps in self.buckets]
         self._works, self._launched = [], [False] * len(self.buckets)
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-        self.overlap = False          # chunk completion does not follow backward order: issue everything in finish()
-        for p, g in pairs:
-            p.grad = g
-            p.register_post_accumulate_grad_hook(self._hook)
+        self.overlap = False          # gradients reach the flat buffer by one gather at the end of backward
         return self
 
     def _seal(self, ps):
@@ -333,7 +330,8 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
         loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos,
                                                loss_outs["matrix"].detach(), relative=args.relative)
     total = (loss + loss_learn) / getattr(args, "accum_iter", 1)         # P/:190,195
-    if grad_sync is not None:
+    flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and optimizer is not None
+    if grad_sync is not None and not flat_sync:
         grad_sync.zero_grad()
     elif optimizer is not None:
         optimizer.zero_grad(set_to_none=True)
@@ -341,6 +339,8 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
         for p in raw.parameters():
             p.grad = None
     total.backward()
+    if flat_sync:
+        optimizer.gather_grads()   # one multi-tensor copy into the flat buffer the all-reduce works on
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
             "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
             "teacher_loss_pred": outs_ema["loss_pred"]}

@@ -113,11 +113,20 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 p.grad = g
 
     @torch.no_grad()
-    def step(self, closure=None):
-        """-> gradient norm before clipping (device scalar)."""
+    def gather_grads(self):
+        """Copy the gradients autograd produced (fresh tensors, no accumulate kernels) into the flat buffer with one
+        multi-tensor launch; data-parallel runs call this at the end of backward so the all-reduce can work on `G`."""
         if self._params[0].grad is not None and self._params[0].grad.data_ptr() != self.gviews[0].data_ptr():
             grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
             torch._foreach_copy_(self.gviews, grads)
+        self._gathered = True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        """-> gradient norm before clipping (device scalar)."""
+        if not getattr(self, "_gathered", False):
+            self.gather_grads()
+        self._gathered = False
         g = self.param_groups[0]
         if self.ema is not None:
             self.ema_w_dev.fill_(1.0 - float(self.ema.decay))
