@@ -70,60 +70,44 @@ __global__ __launch_bounds__(256) void pn_layer1_fwd_kernel(const float* __restr
 }
 
 // ------------------------------------------------------------------ max over the K rows of each group (+argmax)
+// One thread owns 8 channels of ONE group and walks all K rows (8 independent 16-byte loads in flight): no LDS, no
+// barrier; a workgroup covers 256/(C/8) groups.  (The sliced layout the reductions below use needs a barrier and
+// a 1-in-SL combine per group, which made this pass latency-bound at 2x its bandwidth time.)
 template <class T>
-__global__ void group_max_fwd_kernel(const T* __restrict__ in, const float* __restrict__ bias, T* __restrict__ out,
-                                     uint8_t* __restrict__ arg, int G, int K, int C) {
-    extern __shared__ float sm[];  // [SL][C] values, then [SL][C] argk (as float bits)
-    const int tpr = C >> 3, SL = blockDim.x / tpr;
-    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
-    float* sv = sm;
-    int* sa = reinterpret_cast<int*>(sm + SL * C);
-    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+__global__ __launch_bounds__(256) void group_max_fwd_kernel(const T* __restrict__ in, const float* __restrict__ bias,
+                                                            T* __restrict__ out, uint8_t* __restrict__ arg, int G, int K, int C) {
+    const int tpr = C >> 3, gpb = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, gl = threadIdx.x / tpr, c = lane * 8;
+    for (int g = blockIdx.x * gpb + gl; g < G; g += gridDim.x * gpb) {
+        const T* base = in + (size_t)g * K * C + c;
         float best[8];
         int bk[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { best[i] = -INFINITY; bk[i] = 0; }
-        int k = sl;
-        for (; k + 3 * SL < K; k += 4 * SL) {   // four rows in flight per thread: the pass is latency-, not bandwidth-limited otherwise
-            float v0[8], v1[8], v2[8], v3[8];
-            V8<T>::load(in + ((size_t)g * K + k) * C + c, v0);
-            V8<T>::load(in + ((size_t)g * K + k + SL) * C + c, v1);
-            V8<T>::load(in + ((size_t)g * K + k + 2 * SL) * C + c, v2);
-            V8<T>::load(in + ((size_t)g * K + k + 3 * SL) * C + c, v3);
+        int k = 0;
+        for (; k + 8 <= K; k += 8) {
+            float v[8][8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                if (v0[i] > best[i]) { best[i] = v0[i]; bk[i] = k; }
-                if (v1[i] > best[i]) { best[i] = v1[i]; bk[i] = k + SL; }
-                if (v2[i] > best[i]) { best[i] = v2[i]; bk[i] = k + 2 * SL; }
-                if (v3[i] > best[i]) { best[i] = v3[i]; bk[i] = k + 3 * SL; }
-            }
+            for (int u = 0; u < 8; ++u) V8<T>::load(base + (size_t)(k + u) * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    if (v[u][i] > best[i]) { best[i] = v[u][i]; bk[i] = k + u; }   // ascending k: first maximum wins
         }
-        for (; k < K; k += SL) {
+        for (; k < K; ++k) {
             float v[8];
-            V8<T>::load(in + ((size_t)g * K + k) * C + c, v);
+            V8<T>::load(base + (size_t)k * C, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 if (v[i] > best[i]) { best[i] = v[i]; bk[i] = k; }
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { sv[sl * C + c + i] = best[i]; sa[sl * C + c + i] = bk[i]; }
-        __syncthreads();
-        if (sl == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float b = sv[c + i];
-                int kk = sa[c + i];
-                for (int s2 = 1; s2 < SL; ++s2) {
-                    const float v = sv[s2 * C + c + i];
-                    const int k2 = sa[s2 * C + c + i];
-                    if (v > b || (v == b && k2 < kk)) { b = v; kk = k2; }   // first maximum wins
-                }
-                best[i] = bias ? b + bias[c + i] : b;
-                arg[(size_t)g * C + c + i] = (uint8_t)kk;
-            }
-            V8<T>::store(out + (size_t)g * C + c, best);
+        for (int i = 0; i < 8; ++i) {
+            if (bias) best[i] += bias[c + i];
+            arg[(size_t)g * C + c + i] = (uint8_t)bk[i];
         }
-        __syncthreads();
+        V8<T>::store(out + (size_t)g * C + c, best);
     }
 }
 
@@ -246,31 +230,52 @@ __global__ void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __
 
 // pass 2: dy = scale * (g - s1/R - yhat * s2/R)   (scale = gamma*rstd)      -> T (G,K,C)
 //         dt[g,c] = sum_k dy[g,k,c]                                           -> f32 (G,C)   (grad of the broadcast term)
+// Thread = 8 channels of one group, all K rows (the per-group sum stays in registers: no LDS, no barrier).
 template <class T>
-__global__ void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
-                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                          const float* __restrict__ s1, const float* __restrict__ s2, float inv_rows,
-                                          T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C, float slope) {
-    extern __shared__ float sm[];  // [SL][C]
-    const int tpr = C >> 3, SL = blockDim.x / tpr;
-    const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
+__global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __restrict__ y0,
+                                                                 const T* __restrict__ t, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const float* __restrict__ mean,
+                                                                 const float* __restrict__ rstd, const float* __restrict__ s1,
+                                                                 const float* __restrict__ s2, float inv_rows,
+                                                                 T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C,
+                                                                 float slope) {
+    const int tpr = C >> 3, gpb = blockDim.x / tpr;
+    const int lane = threadIdx.x % tpr, gl = threadIdx.x / tpr, c = lane * 8;
     float sc[8], sh[8], mu[8], rs[8], m1[8], m2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i];
         m1[i] = s1[c + i] * inv_rows; m2[i] = s2[c + i] * inv_rows;
     }
-    for (int g = blockIdx.x; g < G; g += gridDim.x) {
+    for (int g = blockIdx.x * gpb + gl; g < G; g += gridDim.x * gpb) {
         float tv[8], gs[8];
         V8<T>::load(t + (size_t)g * C + c, tv);
 #pragma unroll
         for (int i = 0; i < 8; ++i) gs[i] = 0.f;
-        for (int k = sl; k < K; k += SL) {
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+            float v[4][8], d[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const size_t o = ((size_t)g * K + k + u) * C + c;
+                V8<T>::load(y0 + o, v[u]); V8<T>::load(da2 + o, d[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float y = v[u][i] + tv[i];
+                    const float gg = (y * sc[i] + sh[i] > 0.f) ? d[u][i] : slope * d[u][i];
+                    const float r = sc[i] * (gg - m1[i] - (y - mu[i]) * rs[i] * m2[i]);
+                    v[u][i] = r; gs[i] += r;
+                }
+                V8<T>::store(dy + ((size_t)g * K + k + u) * C + c, v[u]);
+            }
+        }
+        for (; k < K; ++k) {
             float v[8], d[8];
             const size_t o = ((size_t)g * K + k) * C + c;
-            V8<T>::load(y0 + o, v);
-            V8<T>::load(da2 + o, d);
+            V8<T>::load(y0 + o, v); V8<T>::load(da2 + o, d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float y = v[i] + tv[i];
@@ -281,17 +286,7 @@ __global__ void bn_bcast_bwd_apply_kernel(const T* __restrict__ da2, const T* __
             V8<T>::store(dy + o, v);
         }
 #pragma unroll
-        for (int i = 0; i < 8; ++i) sm[sl * C + c + i] = gs[i];
-        __syncthreads();
-        if (sl == 0) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                float s = 0.f;
-                for (int q = 0; q < SL; ++q) s += sm[q * C + c + i];
-                dt[(size_t)g * C + c + i] = s;
-            }
-        }
-        __syncthreads();
+        for (int i = 0; i < 8; ++i) dt[(size_t)g * C + c + i] = gs[i];
     }
 }
 
@@ -560,12 +555,13 @@ extern "C" int gm3d_group_max_fwd(const void* in, const float* bias, void* out, 
     int rc = gkc_check(in, out, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
     if (!arg) return GM3D_EINVAL;
-    const size_t lds = (size_t)slices_for(C) * C * 8;
+    const int gpb = 256 / (C / 8) < 1 ? 1 : 256 / (C / 8);
+    int grid = (G + gpb - 1) / gpb; grid = grid > 8192 ? 8192 : grid;
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
-                  hipLaunchKernelGGL(group_max_fwd_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                  hipLaunchKernelGGL(group_max_fwd_kernel<bf16_t>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const bf16_t*)in, bias, (bf16_t*)out, arg, G, K, C),
-                  hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                  hipLaunchKernelGGL(group_max_fwd_kernel<float>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const float*)in, bias, (float*)out, arg, G, K, C));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
@@ -646,14 +642,15 @@ extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const vo
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
     if (!da2 || !scale || !shift || !mean || !rstd || !s1 || !s2 || !dy || !dt) return GM3D_EINVAL;
-    const size_t lds = (size_t)slices_for(C) * C * 4;
     const float inv_rows = 1.0f / ((float)G * (float)K);
+    const int gpb = 256 / (C / 8) < 1 ? 1 : 256 / (C / 8);
+    int grid = (G + gpb - 1) / gpb; grid = grid > 8192 ? 8192 : grid;
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
-                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, s1, s2,
                                      inv_rows, (bf16_t*)dy, dt, G, K, C, slope),
-                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
+                  hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<float>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, s1, s2,
                                      inv_rows, (float*)dy, dt, G, K, C, slope));
     GM3D_CHECK_LAUNCH();
