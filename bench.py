@@ -61,6 +61,22 @@ def algorithmic(name, meta):
     return None
 
 
+def pmc_traffic(kernel, dtype):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc
+    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_e_pmc_fetch_write_per_launch.json), corrected as
+    MI355X_MICROARCH.md prescribes for gfx950: counters are in KB, and FETCH_SIZE reports half of a coalesced stream.
+    Launch-weighted mean over the kernel's shapes in the step.  None when no measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "r01_e_pmc_fetch_write_per_launch.json")
+    if not os.path.exists(path):
+        return None
+    tag = kernel.replace("gm3d_", "gm3d::") + "_kernel"
+    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(tag) and (dtype in r["kernel"] or "<" not in r["kernel"])]
+    n = sum(r["launches"] for r in rows)
+    if not n:
+        return None
+    return sum(r["launches"] * (2.0 * r["FETCH_SIZE_KB_avg"] + r["WRITE_SIZE_KB_avg"]) * 1024.0 for r in rows) / n
+
+
 def make_clouds(B, N, seed, device):
     g = torch.Generator().manual_seed(seed)
     x = torch.rand(B, N, 3, generator=g) * 2 - 1
@@ -99,7 +115,7 @@ def main():
     ap.add_argument("--epoch", type=int, default=200, help="epoch index (200/400: guided-mask branch active)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--bucket-mb", type=int, default=32)
     ap.add_argument("--no-graph", action="store_true",
                     help="eager launches instead of hipGraph replay (the step is ~1000 launches: eager is host-bound)")
@@ -216,11 +232,16 @@ def main():
     if rank == 0:
         dtype = "f32" if args.fp32 else "bf16"
         tsum = timer.summary()[dominant]
-        bound, amount, unit = algorithmic(dominant, tsum["meta"])
+        bound, _, unit = algorithmic(dominant, tsum["meta"])
+        # the kernel runs on several shapes per step (e.g. 8192- and 3200-row token streams): algorithmic work and time
+        # are summed over the timed launches, so `achieved` is total work / total kernel time
+        amount = sum(algorithmic(dominant, m)[1] for _, m in tsum["per_launch"]) / tsum["launches"]
         if bound == "hbm":
             achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
         else:
             achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS[dtype], "TFLOP/s"
+        for v in psum.values():
+            v.pop("per_launch", None)
         per_step = {n: {"launches_per_step": v["launches"] / nprobe,
                         "avg_us": round(v["avg_ms"] * 1e3, 2),
                         "ms_per_step": round(v["total_ms"] / nprobe, 4)} for n, v in psum.items()}
@@ -242,7 +263,7 @@ def main():
                                    "random-init weights" % (args.batch, args.epoch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
-                         "frac": achieved / peak, "traffic": None,
+                         "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype),
                          "avg_launch_us": tsum["avg_ms"] * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
             "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph

@@ -39,7 +39,8 @@ class KernelTimer:
         out = {}
         for name, recs in self.records.items():
             ms = [s.elapsed_time(e) for s, e, _ in recs]
-            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "meta": recs[0][2]}
+            out[name] = {"launches": len(ms), "avg_ms": sum(ms) / len(ms), "total_ms": sum(ms), "meta": recs[0][2],
+                         "per_launch": [(m, r[2]) for m, r in zip(ms, recs)]}
         return out
 
 
