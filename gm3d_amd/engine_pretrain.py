@@ -297,6 +297,17 @@ def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
 
 
 # --------------------------------------------------------------------------- the step
+OVERLAP_EMBED = False   # measured on MI355X: running the student's embed beside the teacher's forward is 5 % SLOWER (12.2 vs 11.6 ms/step)
+_side_streams = {}
+
+
+def _side_stream(device):
+    key = str(device)
+    if key not in _side_streams:
+        _side_streams[key] = torch.cuda.Stream(device=device)
+    return _side_streams[key]
+
+
 def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None, mask_noise=None, augment=True,
                           aug_draws=None, optimizer=None):
     """First half of P/engine_pretrain.py:77-197: augment -> teacher -> mask -> student -> losses -> backward.
@@ -315,14 +326,29 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
     B = samples.shape[0]
     visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
+    overlap = OVERLAP_EMBED and samples.is_cuda
     with amp:
         with torch.no_grad():
             group = teacher.group_divider(samples)  # FPS + KNN once; shared with the student
+        tokens = pos_all = None
+        if overlap:
+            # The student's token embed and positional embed do not depend on the mask: run them on a side stream
+            # beside the teacher's forward (16 blocks of small kernels that cannot fill 256 CUs on their own).
+            main, side = torch.cuda.current_stream(), _side_stream(samples.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                tokens = raw.encoder(group[0])
+                pos_all = raw.embed_pos(group[1])
+        with torch.no_grad():
             outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False)
             mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
                                          total_epoch=args.epochs, noise=mask_noise)
             bool_masked_pos = mask.flatten(1).to(torch.bool)
-        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group)
+        if overlap:
+            main.wait_stream(side)
+            tokens.record_stream(main)
+            pos_all.record_stream(main)
+        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens, pos_all=pos_all)
         M = outs["mask_num"]
         loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"])
         loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]

@@ -309,8 +309,9 @@ class MaskedAutoencoderViT(nn.Module):
             return heads.PosEmbedFn.apply(center, l0.weight, l0.bias, l1.weight, l1.bias, heads._adt())
         return l1(act(linear3(center, l0.weight, l0.bias)))
 
-    def _encode_visible(self, neighborhood, vis_ids, pos_all):
-        tokens = self.encoder(neighborhood)  # B G C
+    def _encode_visible(self, neighborhood, vis_ids, pos_all, tokens=None):
+        if tokens is None:
+            tokens = self.encoder(neighborhood)  # B G C
         return self.blocks(take(tokens, vis_ids), take(pos_all, vis_ids), norm=self.norm_p)
 
     def forward_encoder_point(self, neighborhood, center, mask, num_visible=None):
@@ -333,16 +334,19 @@ class MaskedAutoencoderViT(nn.Module):
         w = c1.weight.squeeze(-1).mean(dim=0)
         return (F.linear(h, w.unsqueeze(0)).squeeze(-1) + c1.bias.mean()).view(B, L)
 
-    def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True):
+    def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True, tokens=None,
+                pos_all=None):
         """pts (B,N,3) f32, mask (B,64) bool (True = masked).  Extra keyword-only conveniences for the
         engine: `num_visible` (static visible count, avoids a host sync), `group` (a previously
         computed (neighborhood, center, neighborhood_org), e.g. the teacher's -- the student sees the
         identical samples), `need_pix_pred=False` (skip the reconstruction decoder whose output the
-        teacher pass never reads, P/engine_pretrain.py:86-94)."""
+        teacher pass never reads, P/engine_pretrain.py:86-94), `tokens` / `pos_all` (this model's token embed and
+        positional embed of all 64 groups when the engine has already evaluated them -- neither depends on the mask)."""
         neighborhood, center, neighborhood_org = group if group is not None else self.group_divider(pts)
         vis_ids, mask_ids = split_ids(mask, num_visible)
-        pos_all = self.embed_pos(center)
-        x_vis = self._encode_visible(neighborhood, vis_ids, pos_all)
+        if pos_all is None:
+            pos_all = self.embed_pos(center)
+        x_vis = self._encode_visible(neighborhood, vis_ids, pos_all, tokens)
         B, _, C = x_vis.shape
         if noaug:
             return x_vis

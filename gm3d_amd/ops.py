@@ -33,6 +33,19 @@ class KernelTimer:
     def wants(self, name):
         return self.only is None or name in self.only
 
+    @staticmethod
+    def bracket_overhead_ms(n=200):
+        """Median elapsed time of an EMPTY event bracket on the current stream: what start/stop recording itself adds to
+        every measured launch (subtract it before comparing with rocprof's kernel durations)."""
+        ev = []
+        for _ in range(n):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); e.record()
+            ev.append((s, e))
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in ev)
+        return ms[len(ms) // 2]
+
     def summary(self):
         """name -> {"launches", "avg_ms", "total_ms", "meta"} (synchronises)."""
         torch.cuda.synchronize()
