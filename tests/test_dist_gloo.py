@@ -32,6 +32,9 @@ def _worker(rank, world, port, q):
         loss.backward()
         sync.finish()
         opt.step()
+    from gm3d_amd.validate import gather_tensor
+    gathered = gather_tensor(torch.full((2, 3), float(rank)))          # validation all-gather (dist_utils.gather_tensor)
+    assert gathered.shape == (4, 3) and gathered[:2].eq(0).all() and gathered[2:].eq(1).all()
     bn = torch.nn.BatchNorm1d(4)
     bn.running_mean.fill_(float(rank + 1))
     broadcast_buffers(bn)
