@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libgm3d_hip.so")
+LIB_PATH = os.environ.get("GM3D_HIP_LIB") or os.path.join(_HERE, "lib", "libgm3d_hip.so")
 
 GM3D_OK, GM3D_EINVAL, GM3D_EUNSUPPORTED, GM3D_ELAUNCH = 0, -1, -2, -3
 GM3D_F32, GM3D_BF16 = 0, 1
@@ -47,6 +47,9 @@ SIGNATURES = {
     "gm3d_lin3_gelu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_lin3_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_rank_loss": [_vp, _vp, _i, _i, _vp, _vp, _vp],
+    "gm3d_pn1_bwd_finalize": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "gm3d_bn_finalize": [_vp, ctypes.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "gm3d_pn1_finalize": [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "gm3d_flat_partial_rows": [ctypes.c_longlong],
     "gm3d_adamw_ema_flat_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _f, _f, _f, _f,
                                  _vp, _f, _vp, _vp, _vp, _vp],

@@ -498,6 +498,106 @@ __global__ __launch_bounds__(64) void rank_loss_kernel(const float* __restrict__
     if (j < M) dp[(size_t)b * M + j] = g;
 }
 
+// ------------------------------------------------------------------ BatchNorm statistic finalisation (one tiny launch)
+// Replaces ~16 scalar PyTorch launches per BatchNorm site: from the summed statistics (train) or the running buffers
+// (eval) to the folded affine the streaming kernels consume, plus nn.BatchNorm1d's running-statistic update
+// (momentum, unbiased variance, num_batches_tracked += 1).  fp64 inside: var = E[y^2] - mean^2 cancels.
+__global__ void bn_finalize_kernel(const float* __restrict__ sums /*[2C] sum, sumsq; may be null in eval*/, double rows,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   long long* __restrict__ nbt, float* __restrict__ scale, float* __restrict__ shift,
+                                   float* __restrict__ mean_out, float* __restrict__ rstd_out, int C, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c == 0 && training && nbt) nbt[0] += 1;
+    if (c >= C) return;
+    double mean, var;
+    if (training) {
+        mean = (double)sums[c] / rows;
+        var = (double)sums[C + c] / rows - mean * mean;
+        if (var < 0.0) var = 0.0;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (rows / (rows - 1.0)));
+    } else {
+        mean = running_mean[c]; var = running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * rstd;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)rstd;
+}
+
+// Layer-1 variant: the statistics of h = x.w^T + b are analytic in the input moments mom9 = sums of
+// (x,y,z, xx,xy,xz, yy,yz,zz) over `rows` rows.  Emits the folded conv weights wf = w*scale, bf = (b-mean)*scale+beta.
+__global__ void pn1_finalize_kernel(const double* __restrict__ mom9, double rows, const float* __restrict__ w /*[C][3]*/,
+                                    const float* __restrict__ b, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    float eps, float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    long long* __restrict__ nbt, float* __restrict__ wf, float* __restrict__ bf,
+                                    float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                    double* __restrict__ mcov /*[12]: mean(3), cov(9) row-major; may be null*/,
+                                    float* __restrict__ xmean /*[3]; may be null*/, int C, int training) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    double m[3] = {0, 0, 0}, cov[3][3] = {{0}};
+    if (training) {
+        for (int i = 0; i < 3; ++i) m[i] = mom9[i] / rows;
+        const double S[3][3] = {{mom9[3], mom9[4], mom9[5]}, {mom9[4], mom9[6], mom9[7]}, {mom9[5], mom9[7], mom9[8]}};
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) cov[i][j] = S[i][j] / rows - m[i] * m[j];
+        if (c == 0) {
+            if (nbt) nbt[0] += 1;
+            if (xmean)
+                for (int i = 0; i < 3; ++i) xmean[i] = (float)m[i];
+            if (mcov) {
+                for (int i = 0; i < 3; ++i) mcov[i] = m[i];
+                for (int i = 0; i < 3; ++i)
+                    for (int j = 0; j < 3; ++j) mcov[3 + 3 * i + j] = cov[i][j];
+            }
+        }
+    }
+    if (c >= C) return;
+    const double wx = w[c * 3], wy = w[c * 3 + 1], wz = w[c * 3 + 2];
+    double mean, var;
+    if (training) {
+        mean = wx * m[0] + wy * m[1] + wz * m[2] + (double)b[c];
+        const double wv[3] = {wx, wy, wz};
+        var = 0.0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) var += wv[i] * cov[i][j] * wv[j];
+        if (var < 0.0) var = 0.0;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * var * (rows / (rows - 1.0)));
+    } else {
+        mean = running_mean[c]; var = running_var[c];
+    }
+    const double rstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * rstd;
+    wf[c * 3] = (float)(wx * sc); wf[c * 3 + 1] = (float)(wy * sc); wf[c * 3 + 2] = (float)(wz * sc);
+    bf[c] = (float)(((double)b[c] - mean) * sc + (double)beta[c]);
+    mean_out[c] = (float)mean;
+    rstd_out[c] = (float)rstd;
+}
+
+// Layer-1 backward tail: q = [t1, t2, Ac_x, Ac_y, Ac_z] (5,C) fp64 sums from pn_layer1_bwd_stats ->
+// dW1[c][j] = k_c * (Ac_j[c] - t2_c * rstd_c * (W cov)[c][j]), k = gamma*rstd; dgamma = t2; dbeta = t1.
+__global__ void pn1_bwd_finalize_kernel(const double* __restrict__ q, const double* __restrict__ mcov,
+                                        const float* __restrict__ w, const float* __restrict__ gamma,
+                                        const float* __restrict__ rstd, float* __restrict__ dw, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double* cov = mcov + 3;
+    const double t1 = q[c], t2 = q[C + c], rs = rstd[c], k = (double)gamma[c] * rs;
+    const double wv[3] = {w[c * 3], w[c * 3 + 1], w[c * 3 + 2]};
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double wc = wv[0] * cov[j] + wv[1] * cov[3 + j] + wv[2] * cov[6 + j];
+        dw[c * 3 + j] = (float)(k * (q[(2 + j) * C + c] - t2 * rs * wc));
+    }
+    dgamma[c] = (float)t2;
+    dbeta[c] = (float)t1;
+}
+
 static inline bool chan_ok(int C) { return C >= 8 && C % 8 == 0 && C <= 1024; }
 static inline int threads_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; if (sl < 1) sl = 1; return sl * tpr; }
 static inline int slices_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; return sl < 1 ? 1 : sl; }
@@ -759,6 +859,41 @@ extern "C" int gm3d_rank_loss(const float* pred, const float* target, int B, int
     if (!pred || !target || !out || !dpred || B < 1 || M < 1) return GM3D_EINVAL;
     if (M > 64) return GM3D_EUNSUPPORTED;
     hipLaunchKernelGGL(rank_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, target, M, out, dpred);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_finalize(const float* sums, double rows, const float* gamma, const float* beta, float eps,
+                                float momentum, float* running_mean, float* running_var, long long* nbt, float* scale,
+                                float* shift, float* mean_out, float* rstd_out, int C, int training, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || !mean_out || !rstd_out || C < 1) return GM3D_EINVAL;
+    if (training && (!sums || rows < 2.0)) return GM3D_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, sums, rows, gamma, beta, eps,
+                       momentum, running_mean, running_var, nbt, scale, shift, mean_out, rstd_out, C, training);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_pn1_finalize(const double* mom9, double rows, const float* w, const float* b, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                 long long* nbt, float* wf, float* bf, float* mean_out, float* rstd_out, double* mcov,
+                                 float* xmean, int C, int training, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!w || !b || !gamma || !beta || !running_mean || !running_var || !wf || !bf || !mean_out || !rstd_out || C < 1) return GM3D_EINVAL;
+    if (training && (!mom9 || rows < 2.0)) return GM3D_EINVAL;
+    hipLaunchKernelGGL(pn1_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, mom9, rows, w, b, gamma, beta,
+                       eps, momentum, running_mean, running_var, nbt, wf, bf, mean_out, rstd_out, mcov, xmean, C, training);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_pn1_bwd_finalize(const double* q, const double* mcov, const float* w, const float* gamma, const float* rstd,
+                                     float* dw, float* dgamma, float* dbeta, int C, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!q || !mcov || !w || !gamma || !rstd || !dw || !dgamma || !dbeta || C < 1) return GM3D_EINVAL;
+    hipLaunchKernelGGL(pn1_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, mcov, w, gamma, rstd, dw,
+                       dgamma, dbeta, C);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

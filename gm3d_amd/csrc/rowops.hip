@@ -11,14 +11,13 @@
 // ~1700 tiny launches (dtype casts, adds, LayerNorm, GELU, bias-grad reductions).  Every one of them is a
 // streaming pass over a (rows, 384|1536) tile; fusing them around the GEMMs leaves ONE HBM pass between
 // two GEMMs.  The residual stream stays fp32; GEMM operands are `T` (bf16 in throughput mode, f32 in
-// parity mode).  One wavefront owns one row (384 = 64 lanes x 6 columns): the row statistics are DPP wave
-// reductions, no LDS, no barrier on the forward path.
+// parity mode).  A 32-lane half-wave owns one row (384 = 32 lanes x 3 quads, 16-byte accesses): the row statistics
+// are DPP reductions, no LDS, no barrier on the forward path.
 #include "common.hpp"
 
 namespace gm3d {
 
 constexpr int LNC = 384;            // model width (trans_dim, models_mae_learn_loss.py:110)
-constexpr int LN_PER_LANE = 6;      // 3 pairs per lane: columns 2*lane + 128*i + {0,1}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #define GM3D_SUM_STEP(CTRL, RM) \
@@ -33,27 +32,53 @@ __device__ __forceinline__ float wave_sum(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-template <class T> struct Pair;
-template <> struct Pair<float> {
-    static __device__ __forceinline__ void load(const float* p, float& a, float& b) {
-        const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y;
+// 4 consecutive elements of `T` as floats: one 16-byte access in f32, one 8-byte access in bf16.
+template <class T> struct Quad;
+template <> struct Quad<float> {
+    static __device__ __forceinline__ void load(const float* p, float* v) {
+        const float4 a = *reinterpret_cast<const float4*>(p); v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
     }
-    static __device__ __forceinline__ void store(float* p, float a, float b) {
-        *reinterpret_cast<float2*>(p) = make_float2(a, b);
+    static __device__ __forceinline__ void store(float* p, const float* v) {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
 };
-template <> struct Pair<bf16_t> {
-    typedef __bf16 v2 __attribute__((ext_vector_type(2)));
-    static __device__ __forceinline__ void load(const bf16_t* p, float& a, float& b) {
-        const v2 v = *reinterpret_cast<const v2*>(p); a = (float)v[0]; b = (float)v[1];
+template <> struct Quad<bf16_t> {
+    typedef __bf16 v4 __attribute__((ext_vector_type(4)));
+    static __device__ __forceinline__ void load(const bf16_t* p, float* v) {
+        const v4 a = *reinterpret_cast<const v4*>(p);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)a[i];
     }
-    static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
-        v2 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b; *reinterpret_cast<v2*>(p) = v;
+    static __device__ __forceinline__ void store(bf16_t* p, const float* v) {
+        v4 a;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = (bf16_t)v[i];
+        *reinterpret_cast<v4*>(p) = a;
     }
 };
 
+// Sum over each 32-lane half of the wave, broadcast to the lanes of that half.
+__device__ __forceinline__ float half_sum(float v, int lane) {
+#define GM3D_SUM_STEP(CTRL, RM) \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, RM, 0xF, false));
+    GM3D_SUM_STEP(0xB1, 0xF)
+    GM3D_SUM_STEP(0x4E, 0xF)
+    GM3D_SUM_STEP(0x141, 0xF)
+    GM3D_SUM_STEP(0x140, 0xF)
+    GM3D_SUM_STEP(0x142, 0xA)  // rows 1,3 += row 0,2: lane 31 = lower half, lane 63 = upper half
+#undef GM3D_SUM_STEP
+    const float lo = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+    const float hi = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+    return lane < 32 ? lo : hi;
+}
+
+constexpr int LN_Q = 12;            // columns per lane: 3 quads at 4*(lane&31) + 128*i
+
 // out_res = res + rowscale[r / rows_per_sample] * (y + bias) + add ;  h = LayerNorm(out_res) * gamma + beta
 // res/out_res fp32; y, add, h are T; any of y / bias / rowscale / add / out_res may be null.
+// A 32-lane half-wave owns one row: every lane moves 16-byte (f32) / 8-byte (bf16) pieces, the row statistics are
+// 5-step DPP reductions, no LDS, no barrier.  Rows past R in the last wave are clamped for the loads and masked
+// for the stores (the DPP steps need the whole wave).
 template <class T>
 __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(const float* __restrict__ res, const T* __restrict__ y,
                                                               const float* __restrict__ bias,
@@ -62,47 +87,61 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(const float* __res
                                                               const float* __restrict__ beta, float eps,
                                                               float* __restrict__ out_res, T* __restrict__ h,
                                                               float* __restrict__ mean, float* __restrict__ rstd, int R) {
-    const int lane = threadIdx.x & 63;
-    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int nwaves = gridDim.x * 4;
-    for (int r = wave; r < R; r += nwaves) {
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int stride = gridDim.x * 8;
+    for (int rb = wbase; rb < R; rb += stride) {
+        const bool valid = rb + half < R;
+        const int r = valid ? rb + half : R - 1;
         const size_t base = (size_t)r * LNC;
         const float rs = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
-        float v[LN_PER_LANE];
+        float v[LN_Q];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int c = 2 * lane + 128 * i;
-            float a = 0.f, b = 0.f;
-            if (res) Pair<float>::load(res + base + c, a, b);
+            const int c = 4 * hl + 128 * i;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (res) Quad<float>::load(res + base + c, a);
             if (y) {
-                float ya, yb;
-                Pair<T>::load(y + base + c, ya, yb);
-                if (bias) { ya += bias[c]; yb += bias[c + 1]; }
-                a += rs * ya; b += rs * yb;
+                float t[4];
+                Quad<T>::load(y + base + c, t);
+                if (bias) {
+                    float bb[4];
+                    Quad<float>::load(bias + c, bb);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) t[j] += bb[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] += rs * t[j];
             }
             if (add) {
-                float pa, pb;
-                Pair<T>::load(add + base + c, pa, pb);
-                a += pa; b += pb;
+                float t[4];
+                Quad<T>::load(add + base + c, t);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] += t[j];
             }
-            v[2 * i] = a; v[2 * i + 1] = b;
-            if (out_res) Pair<float>::store(out_res + base + c, a, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[4 * i + j] = a[j];
+            if (out_res && valid) Quad<float>::store(out_res + base + c, a);
         }
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_PER_LANE; ++i) s += v[i];
-        const float mu = wave_sum(s) * (1.0f / LNC);
+        for (int i = 0; i < LN_Q; ++i) s += v[i];
+        const float mu = half_sum(s, lane) * (1.0f / LNC);
         float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < LN_PER_LANE; ++i) { const float d = v[i] - mu; q += d * d; }
-        const float rsd = rsqrtf(wave_sum(q) * (1.0f / LNC) + eps);
+        for (int i = 0; i < LN_Q; ++i) { const float d = v[i] - mu; q += d * d; }
+        const float rsd = rsqrtf(half_sum(q, lane) * (1.0f / LNC) + eps);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int c = 2 * lane + 128 * i;
-            Pair<T>::store(h + base + c, (v[2 * i] - mu) * rsd * gamma[c] + beta[c],
-                           (v[2 * i + 1] - mu) * rsd * gamma[c + 1] + beta[c + 1]);
+            const int c = 4 * hl + 128 * i;
+            float g[4], b[4], o[4];
+            Quad<float>::load(gamma + c, g);
+            Quad<float>::load(beta + c, b);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[4 * i + j] - mu) * rsd * g[j] + b[j];
+            if (valid) Quad<T>::store(h + base + c, o);
         }
-        if (lane == 0) { mean[r] = mu; rstd[r] = rsd; }
+        if (hl == 0 && valid) { mean[r] = mu; rstd[r] = rsd; }
     }
 }
 
@@ -118,66 +157,86 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(const T* __restric
                                                               const float* __restrict__ rowscale, int rows_per_sample,
                                                               float* __restrict__ dx, T* __restrict__ dy,
                                                               float* __restrict__ acc, float* __restrict__ partial, int R) {
-    __shared__ float red[3][4][LNC];
-    const int lane = threadIdx.x & 63;
-    const int w = threadIdx.x >> 6;
-    const int wave = blockIdx.x * 4 + w;
-    const int nwaves = gridDim.x * 4;
-    float sg[LN_PER_LANE], sb[LN_PER_LANE], sy[LN_PER_LANE];
+    __shared__ float red[3][8][LNC];
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int slot = threadIdx.x >> 5;
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int stride = gridDim.x * 8;
+    float sg[LN_Q], sb[LN_Q], sy[LN_Q], gm[LN_Q];
 #pragma unroll
-    for (int i = 0; i < LN_PER_LANE; ++i) sg[i] = sb[i] = sy[i] = 0.f;
-    float gm[LN_PER_LANE];
+    for (int i = 0; i < LN_Q; ++i) sg[i] = sb[i] = sy[i] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { gm[2 * i] = gamma[2 * lane + 128 * i]; gm[2 * i + 1] = gamma[2 * lane + 128 * i + 1]; }
+    for (int i = 0; i < 3; ++i) Quad<float>::load(gamma + 4 * hl + 128 * i, gm + 4 * i);
 
-    for (int r = wave; r < R; r += nwaves) {
+    for (int rb = wbase; rb < R; rb += stride) {
+        const bool valid = rb + half < R;
+        const int r = valid ? rb + half : R - 1;
+        const float keep = valid ? 1.0f : 0.0f;
         const size_t base = (size_t)r * LNC;
         const float mu = mean[r], rsd = rstd[r];
         const float rs = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
-        float d[LN_PER_LANE], xh[LN_PER_LANE];
+        float d[LN_Q], xh[LN_Q];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int c = 2 * lane + 128 * i;
-            float xa, xb;
-            Pair<T>::load(dh + base + c, d[2 * i], d[2 * i + 1]);
-            Pair<float>::load(x + base + c, xa, xb);
-            xh[2 * i] = (xa - mu) * rsd; xh[2 * i + 1] = (xb - mu) * rsd;
+            const int c = 4 * hl + 128 * i;
+            float xv[4];
+            Quad<T>::load(dh + base + c, d + 4 * i);
+            Quad<float>::load(x + base + c, xv);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { xh[4 * i + j] = (xv[j] - mu) * rsd; d[4 * i + j] *= keep; }
         }
 #pragma unroll
-        for (int i = 0; i < LN_PER_LANE; ++i) {
+        for (int i = 0; i < LN_Q; ++i) {
             sg[i] += d[i] * xh[i];
             sb[i] += d[i];
             const float g = d[i] * gm[i];
             s1 += g; s2 += g * xh[i];
         }
-        const float m1 = wave_sum(s1) * (1.0f / LNC), m2 = wave_sum(s2) * (1.0f / LNC);
+        const float m1 = half_sum(s1, lane) * (1.0f / LNC), m2 = half_sum(s2, lane) * (1.0f / LNC);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int c = 2 * lane + 128 * i;
-            float a = rsd * (d[2 * i] * gm[2 * i] - m1 - xh[2 * i] * m2);
-            float b = rsd * (d[2 * i + 1] * gm[2 * i + 1] - m1 - xh[2 * i + 1] * m2);
-            if (gin) { float ga, gb; Pair<float>::load(gin + base + c, ga, gb); a += ga; b += gb; }
-            Pair<float>::store(dx + base + c, a, b);
-            if (acc) { float pa, pb; Pair<float>::load(acc + base + c, pa, pb); Pair<float>::store(acc + base + c, pa + a, pb + b); }
-            if (dy) {
-                const float ya = rs * a, yb = rs * b;
-                Pair<T>::store(dy + base + c, ya, yb);
-                sy[2 * i] += ya; sy[2 * i + 1] += yb;
+            const int c = 4 * hl + 128 * i;
+            float a[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) a[j] = rsd * (d[4 * i + j] * gm[4 * i + j] - m1 - xh[4 * i + j] * m2);
+            if (gin) {
+                float g4[4];
+                Quad<float>::load(gin + base + c, g4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] += g4[j];
+            }
+            if (valid) {
+                Quad<float>::store(dx + base + c, a);
+                if (acc) {
+                    float p4[4];
+                    Quad<float>::load(acc + base + c, p4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) p4[j] += a[j];
+                    Quad<float>::store(acc + base + c, p4);
+                }
+                if (dy) {
+                    float y4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { y4[j] = rs * a[j]; sy[4 * i + j] += y4[j]; }
+                    Quad<T>::store(dy + base + c, y4);
+                }
             }
         }
     }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const int c = 2 * lane + 128 * i;
-        red[0][w][c] = sg[2 * i]; red[0][w][c + 1] = sg[2 * i + 1];
-        red[1][w][c] = sb[2 * i]; red[1][w][c + 1] = sb[2 * i + 1];
-        red[2][w][c] = sy[2 * i]; red[2][w][c + 1] = sy[2 * i + 1];
+        const int c = 4 * hl + 128 * i;
+        Quad<float>::store(&red[0][slot][c], sg + 4 * i);
+        Quad<float>::store(&red[1][slot][c], sb + 4 * i);
+        Quad<float>::store(&red[2][slot][c], sy + 4 * i);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < 3 * LNC; t += 256) {
         const int k = t / LNC, c = t - k * LNC;
-        partial[((size_t)blockIdx.x * 3 + k) * LNC + c] = (red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c]);
+        partial[((size_t)blockIdx.x * 3 + k) * LNC + c] =
+            ((red[k][0][c] + red[k][1][c]) + (red[k][2][c] + red[k][3][c])) +
+            ((red[k][4][c] + red[k][5][c]) + (red[k][6][c] + red[k][7][c]));
     }
 }
 
@@ -228,35 +287,49 @@ template <class T> __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erf_t<T>(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 
-// g = GELU(f + bias), exact erf form (nn.GELU default).  C % 8 == 0; one thread = 8 consecutive columns.
+// g = GELU(f + bias), exact erf form (nn.GELU default).  C % 8 == 0.  blockDim.x = C/8: thread t owns columns
+// 8t..8t+7 (bias in registers) of every row the block visits, two rows (2 x 16 B per lane) in flight.
 template <class T>
-__global__ __launch_bounds__(256) void bias_gelu_fwd_kernel(const T* __restrict__ f, const float* __restrict__ bias,
-                                                            T* __restrict__ g, int R, int C) {
-    const int cpr = C >> 3;  // 8-column chunks per row
-    const size_t total = (size_t)R * cpr;
-    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
-        const int c = (int)(t % cpr) * 8;
-        const size_t o = (t / cpr) * (size_t)C + c;
-        float v[8];
-        V8<T>::load(f + o, v);
+__global__ void bias_gelu_fwd_kernel(const T* __restrict__ f, const float* __restrict__ bias, T* __restrict__ g, int R, int C) {
+    const int c = threadIdx.x * 8;
+    float bv[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_f<T>(v[i] + bias[c + i]);
-        V8<T>::store(g + o, v);
+    for (int i = 0; i < 8; ++i) bv[i] = bias[c + i];
+    int r = blockIdx.x;
+    for (; r + (int)gridDim.x < R; r += 2 * gridDim.x) {
+        const size_t o0 = (size_t)r * C + c, o1 = (size_t)(r + gridDim.x) * C + c;
+        float v0[8], v1[8];
+        V8<T>::load(f + o0, v0); V8<T>::load(f + o1, v1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { v0[i] = gelu_f<T>(v0[i] + bv[i]); v1[i] = gelu_f<T>(v1[i] + bv[i]); }
+        V8<T>::store(g + o0, v0); V8<T>::store(g + o1, v1);
+    }
+    for (; r < R; r += gridDim.x) {
+        const size_t o0 = (size_t)r * C + c;
+        float v0[8];
+        V8<T>::load(f + o0, v0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v0[i] = gelu_f<T>(v0[i] + bv[i]);
+        V8<T>::store(g + o0, v0);
     }
 }
 
 // df = dg * GELU'(f + bias); partial[blockIdx][c] = sum over this block's rows of df (bias gradient).
-// blockDim = C/8 threads: thread t owns columns 8t..8t+7 for every row the block visits (two rows in flight).
+// blockDim = (C/8, SL): thread (t, sl) owns columns 8t..8t+7 of the rows of slice sl (two rows in flight); the SL
+// slices meet in LDS so the partial matrix stays `gridDim.x` rows while SL x more waves stream.
 template <class T>
 __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ f, const float* __restrict__ bias,
                                      T* __restrict__ df, float* __restrict__ partial, int R, int C) {
+    extern __shared__ float gelu_red[];   // [SL][C]
     const int c = threadIdx.x * 8;
+    const int SL = blockDim.y, sl = threadIdx.y;
+    const int stride = gridDim.x * SL;
     float bv[8], s[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { bv[i] = bias[c + i]; s[i] = 0.f; }
-    int r = blockIdx.x;
-    for (; r + (int)gridDim.x < R; r += 2 * gridDim.x) {
-        const size_t o0 = (size_t)r * C + c, o1 = (size_t)(r + gridDim.x) * C + c;
+    int r = blockIdx.x * SL + sl;
+    for (; r + stride < R; r += 2 * stride) {
+        const size_t o0 = (size_t)r * C + c, o1 = (size_t)(r + stride) * C + c;
         float f0[8], g0[8], f1[8], g1[8];
         V8<T>::load(f + o0, f0); V8<T>::load(dg + o0, g0);
         V8<T>::load(f + o1, f1); V8<T>::load(dg + o1, g1);
@@ -267,7 +340,7 @@ __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restri
         }
         V8<T>::store(df + o0, g0); V8<T>::store(df + o1, g1);
     }
-    for (; r < R; r += gridDim.x) {
+    for (; r < R; r += stride) {
         const size_t o0 = (size_t)r * C + c;
         float f0[8], g0[8];
         V8<T>::load(f + o0, f0); V8<T>::load(dg + o0, g0);
@@ -275,8 +348,17 @@ __global__ void bias_gelu_bwd_kernel(const T* __restrict__ dg, const T* __restri
         for (int i = 0; i < 8; ++i) { g0[i] *= gelu_grad_f<T>(f0[i] + bv[i]); s[i] += g0[i]; }
         V8<T>::store(df + o0, g0);
     }
+    V8<float>::store(gelu_red + (size_t)sl * C + c, s);
+    __syncthreads();
+    if (sl == 0) {
+        for (int k = 1; k < SL; ++k) {
+            float o[8];
+            V8<float>::load(gelu_red + (size_t)k * C + c, o);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) partial[(size_t)blockIdx.x * C + c + i] = s[i];
+            for (int i = 0; i < 8; ++i) s[i] += o[i];
+        }
+        V8<float>::store(partial + (size_t)blockIdx.x * C + c, s);
+    }
 }
 
 // Batched second stage: job j sums partial[j*job_stride + r*pitch + c] over r < nrows into out[j*out_stride + c].
@@ -303,8 +385,8 @@ __global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const float*
     }
 }
 
-static inline int ln_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 512 ? 512 : g); }
-static inline int ln_fwd_grid(int R) { int g = (R + 3) / 4; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per wave
+static inline int ln_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 512 ? 512 : g); }
+static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
 static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
 
 }  // namespace gm3d
@@ -368,16 +450,15 @@ extern "C" int gm3d_bias_gelu_fwd(const void* f, const float* bias, void* g, int
                                   gm3d_stream_t stream) {
     using namespace gm3d;
     if (!f || !bias || !g || R < 0 || C < 8) return GM3D_EINVAL;
-    if (C % 8) return GM3D_EUNSUPPORTED;
+    if (C % 8 || C / 8 > 1024) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (R == 0) return GM3D_OK;
-    const size_t total = (size_t)R * (C / 8);
-    const int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    int grid = (R + 1) / 2; grid = grid > 4096 ? 4096 : grid;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GM3D_BF16)
-        hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)f, bias, (bf16_t*)g, R, C);
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_t>, dim3(grid), dim3(C / 8), 0, st, (const bf16_t*)f, bias, (bf16_t*)g, R, C);
     else
-        hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)f, bias, (float*)g, R, C);
+        hipLaunchKernelGGL(bias_gelu_fwd_kernel<float>, dim3(grid), dim3(C / 8), 0, st, (const float*)f, bias, (float*)g, R, C);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -390,11 +471,13 @@ extern "C" int gm3d_bias_gelu_bwd(const void* dg, const void* f, const float* bi
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (R == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
+    int SL = 1024 / (C / 8); SL = SL > 4 ? 4 : SL;
+    const size_t lds = (size_t)SL * C * sizeof(float);
     if (dtype == GM3D_BF16)
-        hipLaunchKernelGGL(bias_gelu_bwd_kernel<bf16_t>, dim3(gelu_bwd_grid(R)), dim3(C / 8), 0, st, (const bf16_t*)dg,
+        hipLaunchKernelGGL(bias_gelu_bwd_kernel<bf16_t>, dim3(gelu_bwd_grid(R)), dim3(C / 8, SL), lds, st, (const bf16_t*)dg,
                            (const bf16_t*)f, bias, (bf16_t*)df, partial, R, C);
     else
-        hipLaunchKernelGGL(bias_gelu_bwd_kernel<float>, dim3(gelu_bwd_grid(R)), dim3(C / 8), 0, st, (const float*)dg,
+        hipLaunchKernelGGL(bias_gelu_bwd_kernel<float>, dim3(gelu_bwd_grid(R)), dim3(C / 8, SL), lds, st, (const float*)dg,
                            (const float*)f, bias, (float*)df, partial, R, C);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;

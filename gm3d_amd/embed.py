@@ -56,8 +56,10 @@ def splitk_wgrad(dy, x):
     return _finish(part.view(S, N * K), S, N * K).view(N, K)
 
 
-def _gkc(name, fn, meta, *args):
-    _launch(name, meta, fn, *args)
+def _c32(p):
+    """detached, contiguous fp32 view of a parameter/buffer (no launch when it already is one)."""
+    p = p.detach()
+    return p if (p.dtype == torch.float32 and p.is_contiguous()) else p.float().contiguous()
 
 
 class EmbedFn(torch.autograd.Function):
@@ -81,7 +83,9 @@ class EmbedFn(torch.autograd.Function):
         C1, C2, C3, C4 = w1.shape[0], w2.shape[0], w3.shape[0], w4.shape[0]
         W1 = w1.reshape(C1, 3)
         f64 = torch.float64
-        # ---- layer 1 statistics (analytic in the input moments) ----
+        # ---- layer 1 statistics (analytic in the input moments), folded into the conv by one tiny kernel ----
+        f32 = dict(dtype=torch.float32, device=dev)
+        mom9 = mcov = xmean = None
         if training:
             nrows = lib.gm3d_embed_partial_rows(0, R, 0)
             part = torch.empty(nrows, 9, dtype=f64, device=dev)
@@ -89,30 +93,20 @@ class EmbedFn(torch.autograd.Function):
             mom9 = torch.empty(9, dtype=f64, device=dev)
             _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": 9}, lib.gm3d_colsum_finish_f64, _ptr(part), nrows, 9, 9,
                     _ptr(mom9), _stream())
-            mom9 = mom9 / R
-            m = mom9[:3]
-            S = torch.stack([mom9[i] for i in (3, 4, 5, 4, 6, 7, 5, 7, 8)]).view(3, 3)   # (no index tensors: H2D copies cannot be captured)
-            cov = S - torch.outer(m, m)
-            W64 = W1.detach().to(f64)
-            mean1 = W64 @ m + b1.detach().to(f64)
-            var1 = ((W64 @ cov) * W64).sum(1).clamp_min(0.0)
-            with torch.no_grad():
-                rm1.mul_(1 - mom).add_(mean1.to(rm1.dtype), alpha=mom)
-                rv1.mul_(1 - mom).add_((var1 * (R / (R - 1.0))).to(rv1.dtype), alpha=mom)
-                nbt1.add_(1)
-        else:
-            m = S = None
-            mean1, var1 = rm1.to(f64), rv1.to(f64)
-        rstd1 = torch.rsqrt(var1 + eps)
-        scale1 = g1.detach().to(f64) * rstd1
-        wf = (W1.detach().to(f64) * scale1[:, None]).float().contiguous()
-        bf = ((b1.detach().to(f64) - mean1) * scale1 + be1.detach().to(f64)).float().contiguous()
+            mcov = torch.empty(12, dtype=f64, device=dev)
+            xmean = torch.empty(3, **f32)
+        w1c, b1c, g1c, be1c = _c32(W1), _c32(b1), _c32(g1), _c32(be1)
+        wf, bf = torch.empty(C1, 3, **f32), torch.empty(C1, **f32)
+        mean1, rstd1 = torch.empty(C1, **f32), torch.empty(C1, **f32)
+        _launch("gm3d_pn1_finalize", {"C": C1}, lib.gm3d_pn1_finalize, _ptr(mom9), float(R), _ptr(w1c), _ptr(b1c), _ptr(g1c),
+                _ptr(be1c), eps, mom, _ptr(rm1), _ptr(rv1), _ptr(nbt1), _ptr(wf), _ptr(bf), _ptr(mean1), _ptr(rstd1),
+                _ptr(mcov), _ptr(xmean), C1, int(training), _stream())
         a1 = torch.empty(R, C1, dtype=adt, device=dev)
         _launch("gm3d_pn_layer1_fwd", {"R": R, "C": C1, "dtype": str(adt)}, lib.gm3d_pn_layer1_fwd, _ptr(x), _ptr(wf),
                 _ptr(bf), _ptr(a1), R, C1, dt_id, _stream())
         # ---- conv2 + max-pool ----
         W2 = weight_cache.get(w2, adt).reshape(C2, C1)
-        f = torch.addmm(b2.detach().to(adt), a1, W2.t())
+        f = torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
         fg = torch.empty(BG, C2, dtype=adt, device=dev)
         arg1 = torch.empty(BG, C2, dtype=torch.uint8, device=dev)
         _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(f), None,
@@ -120,25 +114,21 @@ class EmbedFn(torch.autograd.Function):
         # ---- conv3 on [global | local] ----
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
         W3g, W3l = W3[:, :C2], W3[:, C2:]
-        t = torch.addmm(b3.detach().to(adt), fg, W3g.t())
+        t = torch.addmm(weight_cache.get(b3, adt), fg, W3g.t())
         y0 = f @ W3l.t()
+        st = None
         if training:
             nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
             part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
             _launch("gm3d_bn_bcast_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
                     _ptr(t), BG, K, C3, _ptr(part), dt_id, _stream())
-            st = _finish(part, nrows, 2 * C3).to(f64) / R
-            mean2 = st[:C3]
-            var2 = (st[C3:] - mean2 * mean2).clamp_min(0.0)
-            with torch.no_grad():
-                rm2.mul_(1 - mom).add_(mean2.to(rm2.dtype), alpha=mom)
-                rv2.mul_(1 - mom).add_((var2 * (R / (R - 1.0))).to(rv2.dtype), alpha=mom)
-                nbt2.add_(1)
-        else:
-            mean2, var2 = rm2.to(f64), rv2.to(f64)
-        rstd2 = torch.rsqrt(var2 + eps)
-        scale2 = (g2.detach().to(f64) * rstd2).float()
-        shift2 = (be2.detach().to(f64) - mean2 * g2.detach().to(f64) * rstd2).float()
+            st = _finish(part, nrows, 2 * C3)
+        g2c, be2c = _c32(g2), _c32(be2)
+        scale2, shift2 = torch.empty(C3, **f32), torch.empty(C3, **f32)
+        mean2, rstd2 = torch.empty(C3, **f32), torch.empty(C3, **f32)
+        _launch("gm3d_bn_finalize", {"C": C3}, lib.gm3d_bn_finalize, _ptr(st), float(R), _ptr(g2c), _ptr(be2c), eps, mom,
+                _ptr(rm2), _ptr(rv2), _ptr(nbt2), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), C3, int(training),
+                _stream())
         a2 = torch.empty(R, C3, dtype=adt, device=dev)
         _launch("gm3d_bn_bcast_apply_relu", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
                 _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, 0.0, dt_id, _stream())
@@ -147,14 +137,14 @@ class EmbedFn(torch.autograd.Function):
         z = a2 @ W4.t()
         tok = torch.empty(BG, C4, dtype=adt, device=dev)
         arg2 = torch.empty(BG, C4, dtype=torch.uint8, device=dev)
-        b4f = b4.detach().float().contiguous()
+        b4f = _c32(b4)
         _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
                 _ptr(b4f), _ptr(tok), _ptr(arg2), BG, K, C4, dt_id, _stream())
         if meta["grad"] and any(ctx.needs_input_grad):
             if not training:
                 raise NotImplementedError("EmbedFn backward is implemented for train-mode BatchNorm only")
-            ctx.save_for_backward(x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, m, S,
-                                  mean1.float(), rstd1.float(), mean2.float(), rstd2.float(), scale2, shift2)
+            ctx.save_for_backward(x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, mcov, xmean,
+                                  mean1, rstd1, mean2, rstd2, scale2, shift2)
             ctx.meta, ctx.dims = meta, (B, G, K, C1, C2, C3, C4)
         return tok.view(B, G, C4)
 
@@ -165,7 +155,7 @@ class EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, dtok):
-        (x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, m, S, mean1, rstd1, mean2, rstd2, scale2,
+        (x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, mcov, xmean, mean1, rstd1, mean2, rstd2, scale2,
          shift2) = ctx.saved_tensors
         adt = ctx.meta["adt"]
         dt_id = _DT[adt]
@@ -217,29 +207,24 @@ class EmbedFn(torch.autograd.Function):
         da1 = df @ W2
         dW2 = splitk_wgrad(df, a1).reshape(w2.shape)
         # layer 1: BN1 + conv(K=3), reductions only
-        W1 = w1.reshape(C1, 3).float().contiguous()
+        W1 = _c32(w1.reshape(C1, 3))
         nrows = lib.gm3d_embed_partial_rows(3, R, C1)
         part = torch.empty(nrows, 5 * C1, dtype=f64, device=dev)
-        b1f = b1.float().contiguous()
-        mf = m.float().contiguous()          # keep alive across the launch (raw pointer)
+        b1f, g1f = _c32(b1), _c32(g1)
         _launch("gm3d_pn_layer1_bwd_stats", {"R": R, "C": C1, "dtype": str(adt)}, lib.gm3d_pn_layer1_bwd_stats, _ptr(da1),
-                _ptr(a1), _ptr(x), _ptr(W1), _ptr(b1f), _ptr(mean1), _ptr(rstd1), _ptr(mf), R, C1, _ptr(part), dt_id,
+                _ptr(a1), _ptr(x), _ptr(W1), _ptr(b1f), _ptr(mean1), _ptr(rstd1), _ptr(xmean), R, C1, _ptr(part), dt_id,
                 _stream())
         q = torch.empty(5 * C1, dtype=f64, device=dev)
         _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": 5 * C1}, lib.gm3d_colsum_finish_f64, _ptr(part), nrows,
                 5 * C1, 5 * C1, _ptr(q), _stream())
-        q = q.view(5, C1)
-        t1, t2, Ac = q[0], q[1], q[2:5]                                 # sum g1, sum g1*hhat, sum g1*(x_j - mean_j)
-        # dh0 = k*(g1 - t1/R - hhat*t2/R), k = gamma*rstd;  dW1[c,j] = sum_r dh0*x_j = sum_r dh0*(x_j - m_j)
-        # (sum_r dh0 = 0), sum_r (x_j - m_j) = 0 and sum_r hhat*(x_j - m_j) = rstd * R * (W1 cov)_j:
-        m64, S64 = m.to(f64), S.to(f64)
-        cov = S64 - torch.outer(m64, m64)
-        W64, rs64 = W1.to(f64), rstd1.to(f64)
-        k = g1.to(f64) * rs64
-        dW1 = k[:, None] * (Ac.t() - (t2 * rs64)[:, None] * (W64 @ cov))
-        dg1, dbe1 = t2.float(), t1.float()
+        # q = [sum g1, sum g1*hhat, sum g1*(x_j - mean_j)];  dh0 = k*(g1 - t1/R - hhat*t2/R), k = gamma*rstd;
+        # dW1[c,j] = sum_r dh0*(x_j - m_j) (sum_r dh0 = 0) and sum_r hhat*(x_j - m_j) = rstd * R * (W1 cov)_j
+        dW1 = torch.empty(C1, 3, dtype=torch.float32, device=dev)
+        dg1, dbe1 = torch.empty(C1, dtype=torch.float32, device=dev), torch.empty(C1, dtype=torch.float32, device=dev)
+        _launch("gm3d_pn1_bwd_finalize", {"C": C1}, lib.gm3d_pn1_bwd_finalize, _ptr(q), _ptr(mcov), _ptr(W1), _ptr(g1f),
+                _ptr(rstd1), _ptr(dW1), _ptr(dg1), _ptr(dbe1), C1, _stream())
         db1 = torch.zeros_like(b1)                                       # bias in front of BatchNorm: exactly zero
-        return (None, None, dW1.float().reshape(w1.shape), db1, dg1, dbe1, dW2, db2, dW3, db3, dg2, dbe2,
+        return (None, None, dW1.reshape(w1.shape), db1, dg1, dbe1, dW2, db2, dW3, db3, dg2, dbe2,
                 dW4.reshape(w4.shape), db4, None, None, None, None, None, None)
 
 

@@ -12,7 +12,7 @@ the whole step safe to replay as a hipGraph on this stack -- see GraphedPretrain
 import torch
 
 from ._capi import lib
-from .embed import _finish, colsum, splitk_wgrad
+from .embed import _c32, _finish, colsum, splitk_wgrad
 from .fused import weight_cache
 from .ops import _launch, _ptr, _stream, _DT
 
@@ -38,7 +38,7 @@ class LinearBiasFn(torch.autograd.Function):
             shp = x.shape
             x2 = x.reshape(-1, shp[-1]).to(adt).contiguous()
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
-            y = torch.addmm(b.detach().to(adt), x2, W.t())
+            y = torch.addmm(weight_cache.get(b, adt), x2, W.t())
             ctx.save_for_backward(x2, w)
             ctx.adt, ctx.shp, ctx.xdt = adt, shp, x.dtype
             return y.view(*shp[:-1], w.shape[0])
@@ -66,12 +66,12 @@ class PosEmbedFn(torch.autograd.Function):
             B, G, _ = center.shape
             R, C = B * G, w0.shape[0]
             x = center.reshape(R, 3).float().contiguous()
-            w0f, b0f = w0.detach().float().contiguous(), b0.detach().float().contiguous()
+            w0f, b0f = _c32(w0), _c32(b0)
             h = torch.empty(R, C, dtype=adt, device=x.device)
             _launch("gm3d_lin3_gelu_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_fwd, _ptr(x), _ptr(w0f),
                     _ptr(b0f), _ptr(h), R, C, _DT[adt], _stream())
             W1 = weight_cache.get(w1, adt)
-            out = torch.addmm(b1.detach().to(adt), h, W1.t())
+            out = torch.addmm(weight_cache.get(b1, adt), h, W1.t())
             ctx.save_for_backward(x, h, w0f, b0f, w1)
             ctx.adt, ctx.dims = adt, (B, G, R, C)
             return out.view(B, G, -1)
@@ -108,28 +108,23 @@ class LossPredHeadFn(torch.autograd.Function):
             K = 32 if R % 32 == 0 else 1
             G = R // K
             dev = x.device
-            f64 = torch.float64
             x2 = x.reshape(R, Cin).to(adt).contiguous()
             W0 = weight_cache.get(w0, adt).reshape(C, Cin)
             y0 = x2 @ W0.t()
-            t = b0.detach().to(adt).unsqueeze(0).expand(G, C).contiguous()
+            t = weight_cache.get(b0, adt).detach().unsqueeze(0).expand(G, C).contiguous()
+            st = None
             if training:
                 nrows = lib.gm3d_embed_partial_rows(1, G, C)
                 part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
                 _launch("gm3d_bn_bcast_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
                         _ptr(t), G, K, C, _ptr(part), _DT[adt], _stream())
-                st = _finish(part, nrows, 2 * C).to(f64) / R
-                mean = st[:C]
-                var = (st[C:] - mean * mean).clamp_min(0.0)
-                with torch.no_grad():
-                    rm.mul_(1 - mom).add_(mean.to(rm.dtype), alpha=mom)
-                    rv.mul_(1 - mom).add_((var * (R / (R - 1.0))).to(rv.dtype), alpha=mom)
-                    nbt.add_(1)
-            else:
-                mean, var = rm.to(f64), rv.to(f64)
-            rstd = torch.rsqrt(var + eps)
-            scale = (gamma.detach().to(f64) * rstd).float()
-            shift = (beta.detach().to(f64) - mean * gamma.detach().to(f64) * rstd).float()
+                st = _finish(part, nrows, 2 * C)
+            f32 = dict(dtype=torch.float32, device=dev)
+            gc, bc = _c32(gamma), _c32(beta)
+            scale, shift, mean, rstd = (torch.empty(C, **f32) for _ in range(4))
+            _launch("gm3d_bn_finalize", {"C": C}, lib.gm3d_bn_finalize, _ptr(st), float(R), _ptr(gc), _ptr(bc), float(eps),
+                    float(mom), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), C,
+                    int(training), _stream())
             a = torch.empty(R, C, dtype=adt, device=dev)
             _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
                     _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
@@ -139,7 +134,7 @@ class LossPredHeadFn(torch.autograd.Function):
             if meta["grad"] and any(ctx.needs_input_grad):
                 if not training:
                     raise NotImplementedError("LossPredHeadFn backward is implemented for train-mode BatchNorm only")
-                ctx.save_for_backward(x2, y0, t, a, w0, gamma, w1, wv, mean.float(), rstd.float(), scale, shift)
+                ctx.save_for_backward(x2, y0, t, a, w0, gamma, w1, wv, mean, rstd, scale, shift)
                 ctx.meta, ctx.dims, ctx.xdt = meta, (B, L, Cin, R, C, G, K), x.dtype
             return out.view(B, L)
 

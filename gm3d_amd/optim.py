@@ -90,13 +90,11 @@ class FlatAdamWEma(torch.optim.Optimizer):
         optimizer kernel rewrites every step (no separate cast launches)."""
         from .fused import weight_cache
         for p, o in zip(self._params, self._offs):
-            if p.dim() >= 2:
-                weight_cache.pin_view(p, self.PS[o:o + p.numel()].view_as(p))
+            weight_cache.pin_view(p, self.PS[o:o + p.numel()].view_as(p))
         if model_ema is not None:
             tparams = dict(model_ema.ema.named_parameters())
             for (name, p), o in zip(self._named, self._offs):
-                if p.dim() >= 2:
-                    weight_cache.pin_view(tparams[name], self.ES[o:o + p.numel()].view_as(p))
+                weight_cache.pin_view(tparams[name], self.ES[o:o + p.numel()].view_as(p))
 
     def flat_grad_views(self):
         """The gradient slots: set `p.grad = view` to have backward accumulate straight into the flat buffer

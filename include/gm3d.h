@@ -234,6 +234,24 @@ int gm3d_adamw_ema_flat_step(float *params, const float *grads, float *exp_avg, 
                              float weight_decay, float beta1, float beta2, float eps, const float *ema_w_dev,
                              float max_norm, float *step_dev, float *partial, float *scal, gm3d_stream_t stream);
 
+/* BatchNorm statistic finalisation in one launch (train: from sums = [sum(C), sumsq(C)] over `rows` rows, with
+ * nn.BatchNorm1d's running-statistic update -- momentum, unbiased variance, num_batches_tracked += 1; eval: from the
+ * running buffers): scale = gamma*rstd, shift = beta - mean*scale, plus mean / rstd for the backward. */
+int gm3d_bn_finalize(const float *sums, double rows, const float *gamma, const float *beta, float eps, float momentum,
+                     float *running_mean, float *running_var, long long *nbt, float *scale, float *shift,
+                     float *mean_out, float *rstd_out, int C, int training, gm3d_stream_t stream);
+/* Same for the K=3 first layer, whose statistics are analytic in the input moments mom9 (gm3d_moments3, summed):
+ * emits the BatchNorm-folded conv wf (C,3) / bf (C), mean / rstd, and mcov = [mean(3), cov(3x3)] fp64 and
+ * xmean (3) f32 for the backward. */
+int gm3d_pn1_finalize(const double *mom9, double rows, const float *w, const float *b, const float *gamma,
+                      const float *beta, float eps, float momentum, float *running_mean, float *running_var,
+                      long long *nbt, float *wf, float *bf, float *mean_out, float *rstd_out, double *mcov,
+                      float *xmean, int C, int training, gm3d_stream_t stream);
+/* Layer-1 backward tail: q (5,C) fp64 = summed gm3d_pn_layer1_bwd_stats partials, mcov from gm3d_pn1_finalize ->
+ * dw (C,3), dgamma (C), dbeta (C). */
+int gm3d_pn1_bwd_finalize(const double *q, const double *mcov, const float *w, const float *gamma, const float *rstd,
+                          float *dw, float *dgamma, float *dbeta, int C, gm3d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
