@@ -136,15 +136,19 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    if world > 1:
+    # GM3D_FORCE_DIST=1: take the data-parallel code path (RCCL process group, bucketed all-reduce, two graphs) with a
+    # single rank -- lets a one-GPU box rehearse exactly what the N>1 launch runs
+    use_dist = world > 1 or os.environ.get("GM3D_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
         print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", local_rank if use_dist else 0)
 
     from gm3d_amd import engine_pretrain as E
     from gm3d_amd import models_mae_learn_loss as M
@@ -156,7 +160,7 @@ def main():
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
     use_graph = not args.no_graph
     optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=model_ema)
-    grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=args.bucket_mb << 20) if world > 1 else None
+    grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=args.bucket_mb << 20) if use_dist else None
     step_args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=not args.fp32, accum_iter=1,
                                 lr=1e-3, min_lr=0.0, warmup_epochs=40)
     torch.manual_seed(1234 + rank)            # per-rank augmentation / mask / DropPath streams
@@ -168,7 +172,7 @@ def main():
                                grad_sync=grad_sync)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -194,7 +198,7 @@ def main():
             use_graph = False
             if grad_sync is not None:
                 grad_sync.overlap = True
-    if world > 1:                 # every rank must take the same path
+    if use_dist:                  # every rank must take the same path
         flag = torch.tensor([1.0 if use_graph else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if use_graph and float(flag) == 0.0:
@@ -224,7 +228,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
@@ -294,7 +298,7 @@ def main():
                          "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype),
                          "avg_launch_us": raw_avg_ms * 1e3, "empty_bracket_us": overhead_ms * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
-            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if world > 1 else "")) if use_graph
+            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if use_dist else "")) if use_graph
             else (graph_note or "eager"),
             "kernel_rooflines": all_roof,
             "tuned_gemm_table": bool(tuned),
@@ -304,7 +308,7 @@ def main():
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
