@@ -1,12 +1,13 @@
 // Multi-head softmax attention (forward + backward) for the Point-MAE token sequences
-// (T <= 64 tokens, head_dim 64, 6 heads) on gfx950 matrix cores.
+// (T <= 128 tokens: 64 patch tokens in pre-training, cls + 64 in fine-tuning; head_dim 64, 6 heads) on gfx950
+// matrix cores.
 //
 // Beneath: timm-0.4.5 Attention.forward -- in-tree twin
 //   Point-MAE_SA3D/models/Point_MAE.py:113-125 (qkv reshape :115, softmax(q k^T * scale) :118-119,
 //   attn @ v :122), used by every Block of TransformerEncoder/TransformerDecoder
 //   (models_mae_learn_loss.py:901-917,959-990).
 //
-// Design (MI355X): a whole (batch, head) problem -- Q,K,V of 64x64 -- fits one CU, so one
+// Design (MI355X): a whole (batch, head) problem -- Q,K,V of (<=128)x64 -- fits one CU, so one
 // workgroup owns one (b,h) and nothing but qkv in / out (+lse) ever crosses HBM: the
 // T x T score matrix lives in MFMA accumulators.  Scores are computed TRANSPOSED
 // (S^T = K Q^T) so that a query is a lane and its keys are registers: the softmax row
@@ -17,6 +18,7 @@
 //   GM3D_F32 : v_mfma_f32_32x32x2_f32, bit-exact f32 FMA chains (parity mode).
 // Backward recomputes P from the saved log-sum-exp; each wave owns one 32-key tile for
 // dK/dV and one 32-query tile for dQ, so there are no atomics and no cross-workgroup sums.
+// Kernels are templated on MT, the number of 32-row tiles the LDS buffers hold (2: T <= 64, 4: T <= 128).
 #include "common.hpp"
 
 namespace gm3d {
@@ -73,9 +75,9 @@ __device__ __forceinline__ bf16x8 cvt8(const f32x16& x, int s, float mul) {
 #define MFMA_BF16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 #define MFMA_F32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
 
-// Cooperative copy of one head's (T,64) slice of qkv into a zero-padded 64-row LDS tile.
-__device__ __forceinline__ void stage_bf16(bf16_t* dst /*[64][VLD]*/, const bf16_t* src, size_t row_stride, int T) {
-    for (int c = threadIdx.x; c < 64 * 8; c += blockDim.x) {
+// Cooperative copy of one head's (T,64) slice of qkv into a zero-padded `rows`-row LDS tile.
+__device__ __forceinline__ void stage_bf16(bf16_t* dst /*[rows][VLD]*/, const bf16_t* src, size_t row_stride, int T, int rows) {
+    for (int c = threadIdx.x; c < rows * 8; c += blockDim.x) {
         const int row = c >> 3, col = (c & 7) * 8;
         *reinterpret_cast<bf16x8*>(dst + row * VLD + col) = row < T ? ld8(src + (size_t)row * row_stride + col) : zero8();
     }
@@ -83,17 +85,18 @@ __device__ __forceinline__ void stage_bf16(bf16_t* dst /*[64][VLD]*/, const bf16
 // f32 tiles use a 64-float pitch with a per-row rotation so that both row-wise and
 // column-wise lane patterns are bank-conflict free: element (r,c) at r*64 + ((c + r) & 63).
 __device__ __forceinline__ int rot(int r, int c) { return r * 64 + ((c + r) & 63); }
-__device__ __forceinline__ void stage_f32(float* dst /*[64*64]*/, const float* src, size_t row_stride, int T) {
-    for (int c = threadIdx.x; c < 64 * 64; c += blockDim.x) {
+__device__ __forceinline__ void stage_f32(float* dst /*[rows*64]*/, const float* src, size_t row_stride, int T, int rows) {
+    for (int c = threadIdx.x; c < rows * 64; c += blockDim.x) {
         const int row = c >> 6, col = c & 63;
         dst[rot(row, col)] = row < T ? src[(size_t)row * row_stride + col] : 0.f;
     }
 }
 
 // ===================================================================== forward, bf16
-__global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                            float* __restrict__ lse, int T, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * VLD];
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int T, int H, float scale) {
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * MT * VLD];
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, qb = threadIdx.x >> 6;  // wave = 32-query block
     const int r = lane & 31, hh = lane >> 5;
@@ -103,53 +106,56 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(const bf16_t* __rest
     const bf16_t* Vg = Kg + (size_t)H * HD;
     const int NK = (T + 31) >> 5;
 
-    stage_bf16(Vs, Vg, rs, T);
+    stage_bf16(Vs, Vg, rs, T, 32 * MT);
     __syncthreads();
 
     // S^T tiles: rows = keys (regs), cols = queries (lanes)
-    f32x16 st0 = zero16(), st1 = zero16();
+    f32x16 st[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) st[t] = zero16();
     const int qrow = 32 * qb + r;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         const bf16x8 bq = qrow < T ? ld8(Qg + (size_t)qrow * rs + 16 * s + 8 * hh) : zero8();
-        const bf16x8 a0 = r < T ? ld8(Kg + (size_t)r * rs + 16 * s + 8 * hh) : zero8();
-        st0 = MFMA_BF16(a0, bq, st0);
-        if (NK > 1) {
-            const bf16x8 a1 = 32 + r < T ? ld8(Kg + (size_t)(32 + r) * rs + 16 * s + 8 * hh) : zero8();
-            st1 = MFMA_BF16(a1, bq, st1);
-        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            if (t < NK) {
+                const bf16x8 a = 32 * t + r < T ? ld8(Kg + (size_t)(32 * t + r) * rs + 16 * s + 8 * hh) : zero8();
+                st[t] = MFMA_BF16(a, bq, st[t]);
+            }
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int k0 = crow(g, hh);
-        st0[g] = k0 < T ? st0[g] * scale : -INFINITY;
-        st1[g] = 32 + k0 < T ? st1[g] * scale : -INFINITY;
-        m = fmaxf(m, fmaxf(st0[g], st1[g]));
-    }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int key = 32 * t + crow(g, hh);
+            st[t][g] = key < T ? st[t][g] * scale : -INFINITY;
+            m = fmaxf(m, st[t][g]);
+        }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        st0[g] = __expf(st0[g] - m);
-        st1[g] = __expf(st1[g] - m);
-        sum += st0[g] + st1[g];
-    }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            st[t][g] = __expf(st[t][g] - m);
+            sum += st[t][g];
+        }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
     f32x16 o0 = zero16(), o1 = zero16();
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        const bf16x8 p0 = cvt8(st0, s, inv);
-        o0 = MFMA_BF16(p0, ld8_col_perm(Vs, VLD, 0, s, hh, r), o0);
-        o1 = MFMA_BF16(p0, ld8_col_perm(Vs, VLD, 0, s, hh, 32 + r), o1);
-        if (NK > 1) {
-            const bf16x8 p1 = cvt8(st1, s, inv);
-            o0 = MFMA_BF16(p1, ld8_col_perm(Vs, VLD, 32, s, hh, r), o0);
-            o1 = MFMA_BF16(p1, ld8_col_perm(Vs, VLD, 32, s, hh, 32 + r), o1);
+    for (int t = 0; t < MT; ++t)
+        if (t < NK) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const bf16x8 p = cvt8(st[t], s, inv);
+                o0 = MFMA_BF16(p, ld8_col_perm(Vs, VLD, 32 * t, s, hh, r), o0);
+                o1 = MFMA_BF16(p, ld8_col_perm(Vs, VLD, 32 * t, s, hh, 32 + r), o1);
+            }
         }
-    }
     // O tile: rows = queries (regs), cols = d (lanes)
     bf16_t* og = out + (size_t)b * T * H * HD + (size_t)h * HD;
 #pragma unroll
@@ -164,47 +170,54 @@ __global__ __launch_bounds__(128) void attn_fwd_bf16_kernel(const bf16_t* __rest
 }
 
 // ===================================================================== forward, f32
-__global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                           float* __restrict__ lse, int T, int H, float scale) {
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void attn_fwd_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out,
+                                                               float* __restrict__ lse, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ROWS = 32 * MT;
     float* Qs = sm;
-    float* Ks = Qs + 64 * 64;
-    float* Vs = Ks + 64 * 64;
+    float* Ks = Qs + ROWS * 64;
+    float* Vs = Ks + ROWS * 64;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int lane = threadIdx.x & 63, qb = threadIdx.x >> 6;
     const int r = lane & 31, hh = lane >> 5;
     const size_t rs = (size_t)3 * H * HD;
     const float* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
     const int NK = (T + 31) >> 5;
-    stage_f32(Qs, Qg, rs, T);
-    stage_f32(Ks, Qg + (size_t)H * HD, rs, T);
-    stage_f32(Vs, Qg + (size_t)2 * H * HD, rs, T);
+    stage_f32(Qs, Qg, rs, T, ROWS);
+    stage_f32(Ks, Qg + (size_t)H * HD, rs, T, ROWS);
+    stage_f32(Vs, Qg + (size_t)2 * H * HD, rs, T, ROWS);
     __syncthreads();
 
-    f32x16 st0 = zero16(), st1 = zero16();
+    f32x16 st[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) st[t] = zero16();
     const int qrow = 32 * qb + r;
     for (int s = 0; s < 32; ++s) {
         const int d = 2 * s + hh;
         const float bq = Qs[rot(qrow, d)];
-        st0 = MFMA_F32(Ks[rot(r, d)], bq, st0);
-        if (NK > 1) st1 = MFMA_F32(Ks[rot(32 + r, d)], bq, st1);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            if (t < NK) st[t] = MFMA_F32(Ks[rot(32 * t + r, d)], bq, st[t]);
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int k0 = crow(g, hh);
-        st0[g] = k0 < T ? st0[g] * scale : -INFINITY;
-        st1[g] = 32 + k0 < T ? st1[g] * scale : -INFINITY;
-        m = fmaxf(m, fmaxf(st0[g], st1[g]));
-    }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int key = 32 * t + crow(g, hh);
+            st[t][g] = key < T ? st[t][g] * scale : -INFINITY;
+            m = fmaxf(m, st[t][g]);
+        }
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        st0[g] = expf(st0[g] - m);
-        st1[g] = expf(st1[g] - m);
-        sum += st0[g] + st1[g];
-    }
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            st[t][g] = expf(st[t][g] - m);
+            sum += st[t][g];
+        }
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
@@ -212,14 +225,13 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
 #pragma unroll
     for (int s = 0; s < 16; ++s) {  // k-step s consumes accumulator register s (key crow(s,hh))
         const int key = crow(s, hh);
-        const float p0 = st0[s] * inv;
-        o0 = MFMA_F32(p0, Vs[rot(key, r)], o0);
-        o1 = MFMA_F32(p0, Vs[rot(key, 32 + r)], o1);
-        if (NK > 1) {
-            const float p1 = st1[s] * inv;
-            o0 = MFMA_F32(p1, Vs[rot(32 + key, r)], o0);
-            o1 = MFMA_F32(p1, Vs[rot(32 + key, 32 + r)], o1);
-        }
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            if (t < NK) {
+                const float p = st[t][s] * inv;
+                o0 = MFMA_F32(p, Vs[rot(32 * t + key, r)], o0);
+                o1 = MFMA_F32(p, Vs[rot(32 * t + key, 32 + r)], o1);
+            }
     }
     float* og = out + (size_t)b * T * H * HD + (size_t)h * HD;
 #pragma unroll
@@ -234,16 +246,19 @@ __global__ __launch_bounds__(128) void attn_fwd_f32_kernel(const float* __restri
 }
 
 // ===================================================================== backward, bf16
-// LDS: Q,K,V,dO tiles (64 x VLD bf16 each) + lse[64] + delta[64].
-__global__ __launch_bounds__(128) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
-                                                            const bf16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                            bf16_t* __restrict__ dqkv, int T, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Qs[64 * VLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * VLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[64 * VLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Ds[64 * VLD];
-    __shared__ float Ls[64];
-    __shared__ float Del[64];
+// LDS (dynamic): Q,K,V,dO tiles (ROWS x VLD bf16 each) + lse[ROWS] + delta[ROWS].
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+                                                                const bf16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                                bf16_t* __restrict__ dqkv, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ROWS = 32 * MT;
+    bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);
+    bf16_t* Ks = Qs + ROWS * VLD;
+    bf16_t* Vs = Ks + ROWS * VLD;
+    bf16_t* Ds = Vs + ROWS * VLD;
+    float* Ls = reinterpret_cast<float*>(Ds + ROWS * VLD);
+    float* Del = Ls + ROWS;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -253,10 +268,10 @@ __global__ __launch_bounds__(128) void attn_bwd_bf16_kernel(const bf16_t* __rest
     const bf16_t* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
     const int NT = (T + 31) >> 5;  // number of 32-row tiles (= waves)
 
-    stage_bf16(Qs, Qg, rs, T);
-    stage_bf16(Ks, Qg + os, rs, T);
-    stage_bf16(Vs, Qg + 2 * os, rs, T);
-    stage_bf16(Ds, Dg, os, T);
+    stage_bf16(Qs, Qg, rs, T, ROWS);
+    stage_bf16(Ks, Qg + os, rs, T, ROWS);
+    stage_bf16(Vs, Qg + 2 * os, rs, T, ROWS);
+    stage_bf16(Ds, Dg, os, T, ROWS);
     {   // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
         const int q = tid >> 1, half = tid & 1;
         float acc = 0.f;
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(128) void attn_bwd_bf16_kernel(const bf16_t* __rest
             }
         }
         acc += __shfl_xor(acc, 1);
-        if (half == 0 && q < 64) {
+        if (half == 0 && q < ROWS) {
             Del[q] = acc;
             Ls[q] = q < T ? lse[((size_t)b * H + h) * T + q] : 0.f;
         }
@@ -361,16 +376,18 @@ __global__ __launch_bounds__(128) void attn_bwd_bf16_kernel(const bf16_t* __rest
 }
 
 // ===================================================================== backward, f32
-__global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                           const float* __restrict__ dout, const float* __restrict__ lse,
-                                                           float* __restrict__ dqkv, int T, int H, float scale) {
+template <int MT>
+__global__ __launch_bounds__(64 * MT) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                               const float* __restrict__ dout, const float* __restrict__ lse,
+                                                               float* __restrict__ dqkv, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int ROWS = 32 * MT;
     float* Qs = sm;
-    float* Ks = Qs + 64 * 64;
-    float* Vs = Ks + 64 * 64;
-    float* Ds = Vs + 64 * 64;
-    float* Ls = Ds + 64 * 64;
-    float* Del = Ls + 64;
+    float* Ks = Qs + ROWS * 64;
+    float* Vs = Ks + ROWS * 64;
+    float* Ds = Vs + ROWS * 64;
+    float* Ls = Ds + ROWS * 64;
+    float* Del = Ls + ROWS;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
@@ -380,17 +397,17 @@ __global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restri
     const float* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
     const int NT = (T + 31) >> 5;
 
-    stage_f32(Qs, Qg, rs, T);
-    stage_f32(Ks, Qg + os, rs, T);
-    stage_f32(Vs, Qg + 2 * os, rs, T);
-    stage_f32(Ds, Dg, os, T);
+    stage_f32(Qs, Qg, rs, T, ROWS);
+    stage_f32(Ks, Qg + os, rs, T, ROWS);
+    stage_f32(Vs, Qg + 2 * os, rs, T, ROWS);
+    stage_f32(Ds, Dg, os, T, ROWS);
     {
         const int q = tid >> 1, half = tid & 1;
         float acc = 0.f;
         if (q < T)
             for (int c = 0; c < 32; ++c) acc += Og[(size_t)q * os + half * 32 + c] * Dg[(size_t)q * os + half * 32 + c];
         acc += __shfl_xor(acc, 1);
-        if (half == 0 && q < 64) {
+        if (half == 0 && q < ROWS) {
             Del[q] = acc;
             Ls[q] = q < T ? lse[((size_t)b * H + h) * T + q] : 0.f;
         }
@@ -477,13 +494,22 @@ __global__ __launch_bounds__(128) void attn_bwd_f32_kernel(const float* __restri
 
 static int attn_check(const void* a, const void* b, int B, int T, int H, int dtype) {
     if (!a || !b || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
-    if (T > 64) return GM3D_EUNSUPPORTED;
+    if (T > 128) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if ((long long)B * H > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
     return GM3D_OK;
 }
 
 }  // namespace gm3d
+
+template <class K, class... A>
+static int launch_attn(K kernel, int grid, int threads, size_t lds, hipStream_t st, A... args) {
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return GM3D_ELAUNCH;
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(threads), lds, st, args...);
+    return hipGetLastError() == hipSuccess ? GM3D_OK : GM3D_ELAUNCH;
+}
 
 extern "C" int gm3d_attention_fwd(const void* qkv, void* out, float* lse, int B, int T, int H, float scale,
                                   int dtype, gm3d_stream_t stream) {
@@ -493,16 +519,14 @@ extern "C" int gm3d_attention_fwd(const void* qkv, void* out, float* lse, int B,
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     const int threads = 64 * ((T + 31) / 32);
+    const int rows = T <= 64 ? 64 : 128;
     if (dtype == GM3D_BF16) {
-        hipLaunchKernelGGL(attn_fwd_bf16_kernel, dim3(B * H), dim3(threads), 0, st, (const bf16_t*)qkv, (bf16_t*)out,
-                           lse, T, H, scale);
-    } else {
-        const size_t lds = sizeof(float) * 3 * 64 * 64;
-        hipLaunchKernelGGL(attn_fwd_f32_kernel, dim3(B * H), dim3(threads), lds, st, (const float*)qkv, (float*)out,
-                           lse, T, H, scale);
+        return T <= 64 ? launch_attn(attn_fwd_bf16_kernel<2>, B * H, threads, 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale)
+                       : launch_attn(attn_fwd_bf16_kernel<4>, B * H, threads, 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale);
     }
-    GM3D_CHECK_LAUNCH();
-    return GM3D_OK;
+    const size_t lds = sizeof(float) * 3 * rows * 64;
+    return T <= 64 ? launch_attn(attn_fwd_f32_kernel<2>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale)
+                   : launch_attn(attn_fwd_f32_kernel<4>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale);
 }
 
 extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,
@@ -514,17 +538,17 @@ extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* 
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     const int threads = 64 * ((T + 31) / 32);
+    const int rows = T <= 64 ? 64 : 128;
     if (dtype == GM3D_BF16) {
-        hipLaunchKernelGGL(attn_bwd_bf16_kernel, dim3(B * H), dim3(threads), 0, st, (const bf16_t*)qkv,
-                           (const bf16_t*)out, (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale);
-    } else {
-        const size_t lds = sizeof(float) * (4 * 64 * 64 + 128);
-        if (hipFuncSetAttribute((const void*)attn_bwd_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return GM3D_ELAUNCH;
-        hipLaunchKernelGGL(attn_bwd_f32_kernel, dim3(B * H), dim3(threads), lds, st, (const float*)qkv,
-                           (const float*)out, (const float*)dout, lse, (float*)dqkv, T, H, scale);
+        const size_t lds = (size_t)4 * rows * VLD * sizeof(bf16_t) + 2 * rows * sizeof(float);
+        return T <= 64 ? launch_attn(attn_bwd_bf16_kernel<2>, B * H, threads, lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale)
+                       : launch_attn(attn_bwd_bf16_kernel<4>, B * H, threads, lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
+                                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale);
     }
-    GM3D_CHECK_LAUNCH();
-    return GM3D_OK;
+    const size_t lds = sizeof(float) * (4 * rows * 64 + 2 * rows);
+    return T <= 64 ? launch_attn(attn_bwd_f32_kernel<2>, B * H, threads, lds, st, (const float*)qkv, (const float*)out,
+                                 (const float*)dout, lse, (float*)dqkv, T, H, scale)
+                   : launch_attn(attn_bwd_f32_kernel<4>, B * H, threads, lds, st, (const float*)qkv, (const float*)out,
+                                 (const float*)dout, lse, (float*)dqkv, T, H, scale);
 }

@@ -232,7 +232,7 @@ def run_embed(enc, point_groups):
     """enc: the Encoder module (parameters in the reference's Conv1d/BatchNorm1d layout)."""
     c0, bn0, _, c1 = enc.first_conv
     c2, bn1, _, c3 = enc.second_conv
-    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) \
         else torch.float32
     meta = {"adt": adt, "training": enc.training, "eps": bn0.eps, "momentum": bn0.momentum,
             "grad": torch.is_grad_enabled()}

@@ -1,0 +1,155 @@
+"""Fine-tune / classification step: Point-MAE_SA3D/engine_finetune.py:70-176 (train_one_epoch),
+:179-215 (evaluate) and the optimizer set-up of main_finetune.py:357-365 (layer-wise lr decay, util/lr_decay.py).
+
+Per iteration, all on the GPU: FPS 8192 -> point_all (1200 for npoints 1024) with the HIP FPS kernel, ONE host-drawn
+random subset of `npoints` of those indices shared by the batch (np.random.choice, like the reference), gather,
+scale-and-translate augmentation, PointTransformer forward under bf16 autocast, cross-entropy, backward,
+gradient clipping, AdamW.  The reference runs fp16 autocast + GradScaler; bf16 needs no loss scaling, so the
+`loss_scaler` argument is accepted for signature compatibility and only its clip/step duty is performed.
+"""
+import math
+import sys
+
+import numpy as np
+import torch
+
+from . import ops
+from .engine_pretrain import train_transforms
+
+POINT_ALL = {1024: 1200, 2048: 2400, 4096: 4800, 8192: 8192}
+
+
+# --------------------------------------------------------------------------- optimizer (util/lr_decay.py)
+def get_layer_id_for_vit(name, num_layers):
+    """P/util/lr_decay.py:65-78.  For this model: cls_token -> 0, blocks.blocks.{i}.* -> i + 1, everything else
+    (encoder.*, pos_embed.*, cls_pos, norm_p.*, cls_head_finetune.*) -> num_layers."""
+    if name in ("cls_token", "pos_embed") or name.startswith("patch_embed"):
+        return 0
+    if name.startswith("blocks"):
+        return int(name.split(".")[2]) + 1
+    return num_layers
+
+
+def param_groups_lrd(model, weight_decay=0.05, no_weight_decay_list=(), layer_decay=0.75, num_layers=12):
+    """Layer-wise lr decay groups (P/util/lr_decay.py:15-62): lr_scale = layer_decay ** (num_layers - layer_id);
+    1-D parameters (and exact names in `no_weight_decay_list`) get weight_decay 0."""
+    scales = [layer_decay ** (num_layers - i) for i in range(num_layers + 1)]
+    groups = {}
+    for n, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        no_decay = p.ndim == 1 or n in no_weight_decay_list
+        lid = get_layer_id_for_vit(n, num_layers)
+        key = "layer_%d_%s" % (lid, "no_decay" if no_decay else "decay")
+        if key not in groups:
+            groups[key] = {"lr_scale": scales[lid], "weight_decay": 0.0 if no_decay else weight_decay, "params": [],
+                           "names": []}
+        groups[key]["params"].append(p)
+        groups[key]["names"].append(n)
+    return list(groups.values())
+
+
+def build_optimizer(model, lr, weight_decay=0.05, layer_decay=0.75):
+    """torch.optim.AdamW(param_groups_lrd(...), lr) as in P/main_finetune.py:359-365 (multi-tensor fused update)."""
+    groups = [{k: v for k, v in g.items() if k != "names"} for g in param_groups_lrd(
+        model, weight_decay, no_weight_decay_list=[{"pos_embed", "cls_token"}], layer_decay=layer_decay)]
+    kw = {"fused": True} if next(model.parameters()).is_cuda else {}
+    return torch.optim.AdamW(groups, lr=lr, **kw)
+
+
+def adjust_learning_rate(optimizer, epoch, args):
+    """P/util/lr_sched.py:11-23 with the per-group lr_scale."""
+    if epoch < args.warmup_epochs:
+        lr = args.lr * epoch / args.warmup_epochs
+    else:
+        lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * \
+            (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
+    for g in optimizer.param_groups:
+        g["lr"] = lr * g["lr_scale"] if "lr_scale" in g else lr
+    return lr
+
+
+# --------------------------------------------------------------------------- the step
+def sample_points(points, npoints, subset=None, rng=np.random):
+    """P/engine_finetune.py:117-134: FPS to point_all, keep a random `npoints`-subset of the FPS order (the same
+    subset for every cloud of the batch), gather.  `subset` injects the index draw (parity tests)."""
+    if npoints not in POINT_ALL:
+        raise NotImplementedError("npoints %d" % npoints)
+    point_all = min(POINT_ALL[npoints], points.size(1))
+    fps_idx = ops.furthest_point_sample(points.contiguous(), point_all)                 # (B, point_all) int32
+    if subset is None:
+        subset = rng.choice(point_all, npoints, False)
+    fps_idx = fps_idx[:, torch.as_tensor(np.asarray(subset), device=points.device, dtype=torch.long)].contiguous()
+    return ops.gather_operation(points.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
+
+
+def finetune_step(model, criterion, optimizer, points, targets, npoints=1024, max_norm=None, bf16=True, subset=None,
+                  aug_draws=None, augment=True, update=True, accum_iter=1):
+    """One iteration of P/engine_finetune.py:108-151.  points (B,N0,3) f32 and targets (B,) on the GPU.
+    -> {'loss', 'grad_norm', 'outputs'} as device tensors (no host sync)."""
+    pts = sample_points(points, npoints, subset=subset)
+    if augment:
+        pts = train_transforms(pts, draws=aug_draws)
+    with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+        outputs = model(pts)
+        loss = criterion(outputs.float(), targets.long())
+    (loss / accum_iter).backward()
+    gnorm = None
+    if update:
+        params = [p for p in model.parameters() if p.grad is not None]
+        if max_norm is not None:
+            gnorm = torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return {"loss": loss.detach(), "grad_norm": gnorm, "outputs": outputs.detach()}
+
+
+def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
+                    mixup_fn=None, log_writer=None, args=None, npoints=0, print_freq=20):
+    """Reference signature (P/engine_finetune.py:70-74).  The loss is read on the host every `print_freq` iterations
+    (the reference syncs on loss.item() every iteration; a non-finite loss still stops the run at the next read)."""
+    model.train(True)
+    accum_iter = getattr(args, "accum_iter", 1)
+    optimizer.zero_grad(set_to_none=True)
+    n_iter = len(data_loader)
+    seen, loss_sum, last = 0, 0.0, None
+    for it, (_taxonomy_ids, _model_ids, data) in enumerate(data_loader):
+        if it % accum_iter == 0:
+            adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+        points = data[0].to(device, non_blocking=True)
+        targets = data[1].to(device, non_blocking=True)
+        out = finetune_step(model, criterion, optimizer, points, targets, npoints=npoints,
+                            max_norm=max_norm if max_norm else None, bf16=getattr(args, "bf16", True),
+                            update=(it + 1) % accum_iter == 0, accum_iter=accum_iter)
+        last = out["loss"]
+        if (it + 1) % print_freq == 0 or it + 1 == n_iter:
+            v = float(last)
+            if not math.isfinite(v):
+                print("Loss is {}, stopping training".format(v))
+                sys.exit(1)
+            loss_sum += v
+            seen += 1
+            if log_writer is not None:
+                log_writer.add_scalar("loss", v, int((it / n_iter + epoch) * 1000))
+    lrs = [g["lr"] for g in optimizer.param_groups]
+    return {"loss": loss_sum / max(seen, 1), "lr": max(lrs)}
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device, npoints=1024, bf16=True):
+    """Top-1 accuracy / mean cross-entropy over a loader of (.., .., (points, label)) batches; test clouds are reduced
+    to `npoints` by FPS alone (P/main_finetune.py validate: misc.fps(points, npoints))."""
+    criterion = torch.nn.CrossEntropyLoss(reduction="sum")
+    model.eval()
+    n, correct, loss = 0, 0, 0.0
+    for batch in data_loader:
+        data = batch[-1]
+        points, target = data[0].to(device), data[1].to(device).long().view(-1)
+        if points.size(1) != npoints:
+            points = ops.fps(points.contiguous(), npoints)[1]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            logits = model(points).float()
+        loss += float(criterion(logits, target))
+        correct += int((logits.argmax(-1) == target).sum())
+        n += target.numel()
+    return {"acc1": 100.0 * correct / max(n, 1), "loss": loss / max(n, 1), "n": n}

@@ -321,7 +321,7 @@ def run_stack(blocks, final_norm, x, pos, training):
     """blocks: iterable of Block modules; final_norm: nn.LayerNorm.  x, pos (B,T,384)."""
     from . import models_mae_learn_loss as M  # drop_path_scale lives there (the tests replay recorded draws through it)
     blocks = list(blocks)
-    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+    adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) \
         or x.dtype == torch.bfloat16 else torch.float32
     B = x.shape[0]
     probs = []

@@ -18,7 +18,7 @@ from .ops import _launch, _ptr, _stream, _DT
 
 
 def _adt():
-    return torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_gpu_dtype() == torch.bfloat16) \
+    return torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) \
         else torch.float32
 
 

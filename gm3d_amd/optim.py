@@ -111,6 +111,37 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 p.grad = g
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Restore from `state_dict()` of a FlatAdamWEma (or of an AdamW over the same parameter order): the moments are
+        copied INTO the flat buffers (torch's default would re-point the state at fresh tensors and break the layout)."""
+        ids = [i for g in state_dict["param_groups"] for i in g["params"]]
+        if len(ids) != len(self._params):
+            raise ValueError("optimizer state has %d parameters, this model %d" % (len(ids), len(self._params)))
+        state = state_dict["state"]
+        step = 0.0
+        for pid, p, o in zip(ids, self._params, self._offs):
+            st = state.get(pid, state.get(str(pid)))
+            if st is None:
+                continue
+            n = p.numel()
+            self.M[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.V[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, float(st["step"]))
+        self.step_dev.fill_(step)
+        g0 = state_dict["param_groups"][0]
+        self.lr_dev.fill_(float(g0["lr"]))
+        for k in ("weight_decay", "betas", "eps"):
+            if k in g0:
+                self.param_groups[0][k] = tuple(g0[k]) if k == "betas" else g0[k]
+
+    @torch.no_grad()
+    def sync_shadows(self):
+        """After parameters were written from outside (checkpoint load): refresh the bf16 GEMM copies."""
+        self.PS.copy_(self.P)
+        if self.E is not None:
+            self.ES.copy_(self.E)
+
+    @torch.no_grad()
     def gather_grads(self):
         """Copy the gradients autograd produced (fresh tensors, no accumulate kernels) into the flat buffer with one
         multi-tensor launch; data-parallel runs call this at the end of backward so the all-reduce can work on `G`."""

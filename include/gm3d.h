@@ -98,7 +98,7 @@ int gm3d_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, 
  * qkv is the (B,T,3,H,64) output of the qkv Linear, out is (B,T,H*64).
  * dtype GM3D_F32 (exact-f32 MFMA, parity mode) or GM3D_BF16 (bf16 MFMA, f32
  * softmax/accumulate).  lse (B,H,T) f32 = log-sum-exp of the scaled scores, saved
- * for backward (may be NULL for inference).  Limits: head_dim == 64, 1 <= T <= 64. */
+ * for backward (may be NULL for inference).  Limits: head_dim == 64, 1 <= T <= 128. */
 int gm3d_attention_fwd(const void *qkv, void *out, float *lse, int B, int T, int H,
                        float scale, int dtype, gm3d_stream_t stream);
 

@@ -115,7 +115,7 @@ def _attn_ref(qkv, H, scale):
     return (attn @ v).transpose(1, 2).reshape(B, T, H * 64)
 
 
-@pytest.mark.parametrize("T", [64, 25, 39, 1, 32, 33])
+@pytest.mark.parametrize("T", [64, 25, 39, 1, 32, 33, 65, 96, 97, 128])
 def test_attention_f32(gops, T):
     torch.manual_seed(T)
     B, H = 5, 6
@@ -131,7 +131,7 @@ def test_attention_f32(gops, T):
     assert (qkv.grad.double() - gref.double()).abs().max() <= 1e-5 * gref.abs().max()
 
 
-@pytest.mark.parametrize("T", [64, 25, 39])
+@pytest.mark.parametrize("T", [64, 25, 39, 65, 128])
 def test_attention_bf16(gops, T):
     torch.manual_seed(100 + T)
     B, H = 4, 6
