@@ -37,7 +37,7 @@ def test_argument_errors_are_detected_before_any_launch():
     assert lib.gm3d_fps(one, 1, 100000, 64, one, None, None) == GM3D_EUNSUPPORTED
     assert lib.gm3d_knn(one, one, 1, 8, 2, 9, None, one, None) == GM3D_EINVAL          # k > N
     assert lib.gm3d_knn(one, one, 1, 1024, 2, 65, None, one, None) == GM3D_EUNSUPPORTED
-    assert lib.gm3d_attention_fwd(one, one, None, 1, 65, 6, 0.125, 1, None) == GM3D_EUNSUPPORTED
+    assert lib.gm3d_attention_fwd(one, one, None, 1, 129, 6, 0.125, 1, None) == GM3D_EUNSUPPORTED
     assert lib.gm3d_attention_fwd(one, one, None, 1, 64, 6, 0.125, 7, None) == GM3D_EINVAL
     assert lib.gm3d_chamfer_fwd(one, one, 1, 0, 32, one, one, one, one, None) == GM3D_EINVAL
 
