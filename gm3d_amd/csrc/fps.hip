@@ -7,27 +7,77 @@
 //
 // Design (MI355X): one workgroup per cloud; the cloud and its running-min array live
 // in registers for the whole launch (single HBM read, 12 B/point); every one of the
-// npoint-1 dependent steps is  {register scan -> DPP wave max on a packed 64-bit key ->
-// one LDS slot per wave -> one barrier}.  No global-memory round trip inside the loop.
+// npoint-1 dependent steps is  {packed-fp32 register scan -> DPP wave max/argmin ->
+// one LDS key per wave -> one barrier -> 16-lane row reduction}.  No global-memory round trip
+// inside the loop (clouds up to 8192 points keep an LDS copy for the winner's coordinates).
 #include "common.hpp"
 
 namespace gm3d {
 
-struct __attribute__((aligned(16))) FpsSlot {
-    unsigned long long key;
-    float x, y, z;
-    float pad[3];
-};
+typedef float float2v __attribute__((ext_vector_type(2)));
 
-// key = (float bits of running-min distance) << 32 | ~index : the unsigned maximum is
-// the largest distance, ties -> lowest index.  key 0 = "no candidate" (every point
-// skipped), which decodes to index 0 like upstream's besti=0/best=-1 start.
-template <int T, int PPT>
+// Wave-wide reductions by DPP (result uniform in every lane).  Rows that a step does not write keep `old` = v.
+// The cross-lane move is evaluated ONCE per step into a temporary, outside any conditional: a DPP move under a
+// divergent EXEC mask reads its neighbours as invalid lanes.
+template <int CTRL, int RM> __device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float(dpp_u32<CTRL, RM>(__float_as_uint(v), __float_as_uint(v)));
+}
+template <int CTRL, int RM> __device__ __forceinline__ int dpp_i32(int v) {
+    return (int)dpp_u32<CTRL, RM>((unsigned)v, (unsigned)v);
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+    { const float o = dpp_f32<0xB1, 0xF>(v); v = fmaxf(v, o); }
+    { const float o = dpp_f32<0x4E, 0xF>(v); v = fmaxf(v, o); }
+    { const float o = dpp_f32<0x141, 0xF>(v); v = fmaxf(v, o); }
+    { const float o = dpp_f32<0x140, 0xF>(v); v = fmaxf(v, o); }
+    { const float o = dpp_f32<0x142, 0xA>(v); v = fmaxf(v, o); }
+    { const float o = dpp_f32<0x143, 0xC>(v); v = fmaxf(v, o); }
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+    { const int o = dpp_i32<0xB1, 0xF>(v); v = min(v, o); }
+    { const int o = dpp_i32<0x4E, 0xF>(v); v = min(v, o); }
+    { const int o = dpp_i32<0x141, 0xF>(v); v = min(v, o); }
+    { const int o = dpp_i32<0x140, 0xF>(v); v = min(v, o); }
+    { const int o = dpp_i32<0x142, 0xA>(v); v = min(v, o); }
+    { const int o = dpp_i32<0x143, 0xC>(v); v = min(v, o); }
+    return __builtin_amdgcn_readlane(v, 63);
+}
+// max of a 64-bit key over each 16-lane row (4 DPP steps), every lane of the row gets the result
+__device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k) {
+#define GM3D_STEP(CTRL)                                                             \
+    {                                                                               \
+        unsigned lo = (unsigned)k, hi = (unsigned)(k >> 32);                        \
+        unsigned olo = dpp_u32<CTRL, 0xF>(lo, lo), ohi = dpp_u32<CTRL, 0xF>(hi, hi);\
+        unsigned long long o = ((unsigned long long)ohi << 32) | olo;               \
+        k = o > k ? o : k;                                                          \
+    }
+    GM3D_STEP(0xB1) GM3D_STEP(0x4E) GM3D_STEP(0x141) GM3D_STEP(0x140)
+#undef GM3D_STEP
+    return k;
+}
+
+// key = (float bits of running-min distance) << 32 | ~index : the unsigned maximum is the largest distance, ties ->
+// lowest index.  key 0 = "no candidate" (every point skipped), which decodes to index 0 like upstream's
+// besti=0/best=-1 start.
+//
+// One step of the dependent chain, per wave (the launch is bound by ONE CU's VALU issue rate -- a cloud is one
+// workgroup -- so the step is written for instruction count):
+//   scan    PPT points as packed pairs: v_pk_add/v_pk_mul_f32 for ((dx*dx + dy*dy) + dz*dz) (separately rounded,
+//           identical to the scalar contract), v_min + compare/select of (best, index) only -- the winner's
+//           coordinates are NOT carried through the selects, they are re-read from an LDS copy of the cloud;
+//           skipped points (|p|^2 <= 1e-3) carry tmin = -1 and never win, so the scan has no branches;
+//   reduce  wave max of `best` (f32 DPP), then wave min of the index among the lanes that hold it;
+//   publish one 64-bit key per wave, ONE barrier (double-buffered slots), lanes 0..NW-1 of every row re-read the
+//           slots and finish with a 4-step row reduction.
+template <int T, int PPT, bool LDS_CLOUD>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                 int32_t* __restrict__ idx_out,
                                                 float* __restrict__ centers) {
     constexpr int NW = T / GM3D_WAVE;
-    __shared__ FpsSlot slots[2][NW];
+    static_assert(NW <= 16 && PPT % 2 == 0, "one 16-lane row holds the per-wave keys; points are scanned in pairs");
+    __shared__ unsigned long long slots[2][16];
+    extern __shared__ float cloud[];   // [3*N] when LDS_CLOUD
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -37,20 +87,20 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     int32_t* out = idx_out + (size_t)b * npoint;
     float* cen = centers ? centers + (size_t)b * npoint * 3 : nullptr;
 
-    float px[PPT], py[PPT], pz[PPT], tmin[PPT];
-    bool ok[PPT];
+    float2v px[PPT / 2], py[PPT / 2], pz[PPT / 2];
+    float tmin[PPT];
 #pragma unroll
     for (int i = 0; i < PPT; ++i) {
         const int k = tid + i * T;
         const bool in = k < N;
-        px[i] = in ? p[(size_t)k * 3 + 0] : 0.f;
-        py[i] = in ? p[(size_t)k * 3 + 1] : 0.f;
-        pz[i] = in ? p[(size_t)k * 3 + 2] : 0.f;
-        const float mag = __fadd_rn(__fadd_rn(__fmul_rn(px[i], px[i]), __fmul_rn(py[i], py[i])),
-                                    __fmul_rn(pz[i], pz[i]));
-        ok[i] = in && (mag > 1e-3f);
-        tmin[i] = 1e10f;
+        const float x = in ? p[(size_t)k * 3 + 0] : 0.f, y = in ? p[(size_t)k * 3 + 1] : 0.f, z = in ? p[(size_t)k * 3 + 2] : 0.f;
+        px[i >> 1][i & 1] = x; py[i >> 1][i & 1] = y; pz[i >> 1][i & 1] = z;
+        const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
+        tmin[i] = (in && mag > 1e-3f) ? 1e10f : -1.0f;
+        if (LDS_CLOUD && in) { cloud[k * 3 + 0] = x; cloud[k * 3 + 1] = y; cloud[k * 3 + 2] = z; }
     }
+    if (tid < 32) slots[tid >> 4][tid & 15] = 0ull;
+    __syncthreads();
 
     float ox = p[0], oy = p[1], oz = p[2];
     if (tid == 0) {
@@ -59,39 +109,31 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
     }
 
     for (int j = 1; j < npoint; ++j) {
-        float best = -1.0f, bx = px[0], by = py[0], bz = pz[0];
+        float best = -1.0f;
         int bk = tid;
+        const float2v o2x = {ox, ox}, o2y = {oy, oy}, o2z = {oz, oz};
 #pragma unroll
-        for (int i = 0; i < PPT; ++i) {
-            if (ok[i]) {
-                const float d = sqdist3(px[i], py[i], pz[i], ox, oy, oz);
-                const float t = d < tmin[i] ? d : tmin[i];
+        for (int h = 0; h < PPT / 2; ++h) {
+            const float2v dx = px[h] - o2x, dy = py[h] - o2y, dz = pz[h] - o2z;
+            const float2v d = (dx * dx + dy * dy) + dz * dz;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = 2 * h + e;
+                const float t = __builtin_fminf(d[e], tmin[i]);
                 tmin[i] = t;
-                if (t > best) { best = t; bk = tid + i * T; bx = px[i]; by = py[i]; bz = pz[i]; }
+                if (t > best) { best = t; bk = tid + i * T; }
             }
         }
-        const unsigned long long key =
-            best < 0.f ? 0ull : (((unsigned long long)__float_as_uint(best) << 32) | (unsigned)(~(unsigned)bk));
-        const unsigned long long wkey = wave_max_u64(key);
-        const bool owner = wkey != 0ull ? (key == wkey) : (lane == 0);
-        FpsSlot* s = &slots[j & 1][wave];
-        if (owner) {
-            s->key = wkey;
-            // all-skipped wave: lane 0 publishes its slot-0 point (thread 0 owns point 0)
-            s->x = wkey != 0ull ? bx : px[0];
-            s->y = wkey != 0ull ? by : py[0];
-            s->z = wkey != 0ull ? bz : pz[0];
-        }
+        const float m = wave_max_f32(best);
+        const int mi = wave_min_i32(best == m ? bk : 0x7fffffff);
+        if (lane == 0)
+            slots[j & 1][wave] = m < 0.f ? 0ull : (((unsigned long long)__float_as_uint(m) << 32) | (unsigned)(~(unsigned)mi));
         __syncthreads();
-        unsigned long long fk = slots[j & 1][0].key;
-        int fw = 0;
-#pragma unroll
-        for (int w = 1; w < NW; ++w) {
-            const unsigned long long kw = slots[j & 1][w].key;
-            if (kw > fk) { fk = kw; fw = w; }
-        }
-        ox = slots[j & 1][fw].x; oy = slots[j & 1][fw].y; oz = slots[j & 1][fw].z;
-        const int old = fk != 0ull ? (int)(~(unsigned)fk) : 0;
+        unsigned long long fk = row_max_u64(slots[j & 1][lane & 15]);     // slots >= NW stay 0
+        const unsigned flo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fk);
+        const int old = (__builtin_amdgcn_readfirstlane((int)(unsigned)(fk >> 32)) | (int)flo) != 0 ? (int)(~flo) : 0;
+        if (LDS_CLOUD) { ox = cloud[old * 3 + 0]; oy = cloud[old * 3 + 1]; oz = cloud[old * 3 + 2]; }
+        else { ox = p[(size_t)old * 3 + 0]; oy = p[(size_t)old * 3 + 1]; oz = p[(size_t)old * 3 + 2]; }
         if (tid == 0) {
             out[j] = old;
             if (cen) { cen[(size_t)j * 3 + 0] = ox; cen[(size_t)j * 3 + 1] = oy; cen[(size_t)j * 3 + 2] = oz; }
@@ -131,7 +173,15 @@ __global__ void gather_points_grad_kernel(const float* __restrict__ gout, const 
 
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, float* centers, hipStream_t st) {
-    hipLaunchKernelGGL((fps_kernel<T, PPT>), dim3(B), dim3(T), 0, st, xyz, N, npoint, idx, centers);
+    const size_t lds = (size_t)N * 3 * sizeof(float);
+    if (lds <= 100 * 1024) {                // the cloud fits beside the slots: winner coordinates come from LDS
+        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)fps_kernel<T, PPT, true>,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GM3D_ELAUNCH;
+        hipLaunchKernelGGL((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, idx, centers);
+    } else {
+        hipLaunchKernelGGL((fps_kernel<T, PPT, false>), dim3(B), dim3(T), 0, st, xyz, N, npoint, idx, centers);
+    }
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -146,10 +196,12 @@ extern "C" int gm3d_fps(const float* xyz, int B, int N, int npoint, int32_t* idx
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     if (N <= 256) return launch_fps<64, 4>(xyz, B, N, npoint, idx, centers, st);
+    // thread / points-per-thread shapes measured on MI355X (tools/fps_bench.py): the step is bound by one CU's VALU issue
+    // plus the per-wave reduction chain, so large clouds prefer fewer, fatter waves
     if (N <= 1024) return launch_fps<256, 4>(xyz, B, N, npoint, idx, centers, st);
     if (N <= 2048) return launch_fps<256, 8>(xyz, B, N, npoint, idx, centers, st);
     if (N <= 4096) return launch_fps<512, 8>(xyz, B, N, npoint, idx, centers, st);
-    if (N <= 8192) return launch_fps<1024, 8>(xyz, B, N, npoint, idx, centers, st);
+    if (N <= 8192) return launch_fps<512, 16>(xyz, B, N, npoint, idx, centers, st);
     return launch_fps<1024, 16>(xyz, B, N, npoint, idx, centers, st);
 }
 

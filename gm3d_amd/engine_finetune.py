@@ -49,11 +49,17 @@ def param_groups_lrd(model, weight_decay=0.05, no_weight_decay_list=(), layer_de
     return list(groups.values())
 
 
-def build_optimizer(model, lr, weight_decay=0.05, layer_decay=0.75):
-    """torch.optim.AdamW(param_groups_lrd(...), lr) as in P/main_finetune.py:359-365 (multi-tensor fused update)."""
+def build_optimizer(model, lr, weight_decay=0.05, layer_decay=0.75, capturable=False):
+    """torch.optim.AdamW(param_groups_lrd(...), lr) as in P/main_finetune.py:359-365 (multi-tensor fused update).
+    capturable=True: per-group learning rates live in device tensors (hipGraph capture)."""
     groups = [{k: v for k, v in g.items() if k != "names"} for g in param_groups_lrd(
         model, weight_decay, no_weight_decay_list=[{"pos_embed", "cls_token"}], layer_decay=layer_decay)]
-    kw = {"fused": True} if next(model.parameters()).is_cuda else {}
+    dev = next(model.parameters()).device
+    kw = {"fused": True} if dev.type == "cuda" else {}
+    if capturable:
+        kw["capturable"] = True
+        for g in groups:
+            g["lr"] = torch.tensor(float(lr), dtype=torch.float32, device=dev)
     return torch.optim.AdamW(groups, lr=lr, **kw)
 
 
@@ -65,7 +71,11 @@ def adjust_learning_rate(optimizer, epoch, args):
         lr = args.min_lr + (args.lr - args.min_lr) * 0.5 * \
             (1.0 + math.cos(math.pi * (epoch - args.warmup_epochs) / (args.epochs - args.warmup_epochs)))
     for g in optimizer.param_groups:
-        g["lr"] = lr * g["lr_scale"] if "lr_scale" in g else lr
+        v = lr * g["lr_scale"] if "lr_scale" in g else lr
+        if torch.is_tensor(g["lr"]):
+            g["lr"].fill_(v)                      # capturable optimizer: the captured update reads this tensor
+        else:
+            g["lr"] = v
     return lr
 
 
@@ -79,7 +89,9 @@ def sample_points(points, npoints, subset=None, rng=np.random):
     fps_idx = ops.furthest_point_sample(points.contiguous(), point_all)                 # (B, point_all) int32
     if subset is None:
         subset = rng.choice(point_all, npoints, False)
-    fps_idx = fps_idx[:, torch.as_tensor(np.asarray(subset), device=points.device, dtype=torch.long)].contiguous()
+    if not torch.is_tensor(subset):                     # a device LongTensor is used as is (graph capture: static input)
+        subset = torch.as_tensor(np.asarray(subset), dtype=torch.long).to(points.device)
+    fps_idx = fps_idx.index_select(1, subset).contiguous()
     return ops.gather_operation(points.transpose(1, 2).contiguous(), fps_idx).transpose(1, 2).contiguous()
 
 
@@ -102,6 +114,48 @@ def finetune_step(model, criterion, optimizer, points, targets, npoints=1024, ma
         optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return {"loss": loss.detach(), "grad_norm": gnorm, "outputs": outputs.detach()}
+
+
+class GraphedFinetuneStep:
+    """The fine-tune iteration captured once as a hipGraph and replayed: at the reference's batch sizes (32-40 clouds) the
+    step is a few hundred short launches and the host cannot keep the GPU fed.  Static inputs: the raw clouds, the
+    labels and the random FPS subset (drawn on the host per call, copied in); the augmentation and DropPath/Dropout draws
+    use the graph-safe device generator.  Needs an optimizer built with capturable=True (build_optimizer(...,
+    capturable=True)): its learning rates are device tensors that adjust_learning_rate fills in place."""
+
+    def __init__(self, model, criterion, optimizer, example_points, example_targets, npoints=1024, max_norm=None, bf16=True,
+                 warmup_iters=3, rng=np.random):
+        self.model, self.criterion, self.opt = model, criterion, optimizer
+        self.npoints, self.max_norm, self.bf16, self.rng = npoints, max_norm, bf16, rng
+        self.point_all = min(POINT_ALL[npoints], example_points.size(1))
+        self.points = example_points.clone()
+        self.targets = example_targets.clone()
+        self.subset = torch.zeros(npoints, dtype=torch.long, device=example_points.device)
+        self._draw()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                self._body()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = self._body()
+
+    def _draw(self):
+        self.subset.copy_(torch.from_numpy(self.rng.choice(self.point_all, self.npoints, False).astype(np.int64)))
+
+    def _body(self):
+        return finetune_step(self.model, self.criterion, self.opt, self.points, self.targets, npoints=self.npoints,
+                             max_norm=self.max_norm, bf16=self.bf16, subset=self.subset)
+
+    def __call__(self, points, targets):
+        self.points.copy_(points, non_blocking=True)
+        self.targets.copy_(targets, non_blocking=True)
+        self._draw()
+        self.graph.replay()
+        return self.out
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,

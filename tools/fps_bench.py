@@ -1,0 +1,20 @@
+import torch, sys, os
+sys.path.insert(0, "/root/repo")
+from gm3d_amd import ops
+from bench import make_clouds
+x = make_clouds(32, 8192, 1, torch.device("cuda"))
+for _ in range(3): ops.fps(x, 1200)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10): ops.fps(x, 1200)
+e1.record(); torch.cuda.synchronize()
+t8 = e0.elapsed_time(e1) * 100
+x = make_clouds(128, 1024, 1, torch.device("cuda"))
+for _ in range(3): ops.fps(x, 64)
+torch.cuda.synchronize()
+e0.record()
+for _ in range(20): ops.fps(x, 64)
+e1.record(); torch.cuda.synchronize()
+print("cfg", os.environ.get("GM3D_FPS_CFG"), "fps 1024->64 B=128: %.1f us" % (e0.elapsed_time(e1) * 50), end="; ")
+print("cfg", os.environ.get("GM3D_FPS_CFG"), "fps 8192->1200 B=32: %.1f us" % t8)
