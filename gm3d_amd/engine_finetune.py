@@ -124,9 +124,11 @@ class GraphedFinetuneStep:
     capturable=True)): its learning rates are device tensors that adjust_learning_rate fills in place."""
 
     def __init__(self, model, criterion, optimizer, example_points, example_targets, npoints=1024, max_norm=None, bf16=True,
-                 warmup_iters=3, rng=np.random):
+                 warmup_iters=3, rng=np.random, augment=True):
+        """The `warmup_iters` un-captured iterations are real optimisation steps on the example batch (the allocator and
+        the optimizer state must be warm before capture): pass warmup_iters=0 when the optimizer state already exists."""
         self.model, self.criterion, self.opt = model, criterion, optimizer
-        self.npoints, self.max_norm, self.bf16, self.rng = npoints, max_norm, bf16, rng
+        self.npoints, self.max_norm, self.bf16, self.rng, self.augment = npoints, max_norm, bf16, rng, augment
         self.point_all = min(POINT_ALL[npoints], example_points.size(1))
         self.points = example_points.clone()
         self.targets = example_targets.clone()
@@ -148,7 +150,7 @@ class GraphedFinetuneStep:
 
     def _body(self):
         return finetune_step(self.model, self.criterion, self.opt, self.points, self.targets, npoints=self.npoints,
-                             max_norm=self.max_norm, bf16=self.bf16, subset=self.subset)
+                             max_norm=self.max_norm, bf16=self.bf16, subset=self.subset, augment=self.augment)
 
     def __call__(self, points, targets):
         self.points.copy_(points, non_blocking=True)

@@ -185,3 +185,41 @@ def test_evaluate_and_checkpoint_roundtrip(tmp_path, M):
     assert C.load_checkpoint(path, pm2, opt2) == 4
     b = EF.evaluate(loader, pm2, "cuda", npoints=1024, bf16=False)
     assert a == b
+
+
+def test_graph_replay_equals_eager(M):
+    """hipGraph replay of the fine-tune iteration against the same iterations launched eagerly (DropPath / Dropout /
+    augmentation off so both sides are deterministic; the FPS subset comes from identically seeded host generators)."""
+    from gm3d_amd import engine_finetune as EF
+    crit = nn.CrossEntropyLoss()
+    batches = [clouds.gaussian(8, 2048, seed=50 + i).cuda() for i in range(3)]
+    targets = (torch.arange(8).cuda() * 3) % 40
+    args = SimpleNamespace(lr=1e-3, min_lr=1e-6, warmup_epochs=0, epochs=300)
+
+    def run(graphed):
+        pm = build(seed=9, drop_path=0.0)
+        pm.train()
+        opt = EF.build_optimizer(pm, lr=1e-3, capturable=True)
+        EF.adjust_learning_rate(opt, 5.0, args)
+        rng = np.random.RandomState(7)
+        losses = []
+        if graphed:
+            # warm-up iterations are real steps: give the eager side the same three
+            g = EF.GraphedFinetuneStep(pm, crit, opt, batches[0], targets, npoints=1024, max_norm=10.0, bf16=False, rng=rng,
+                                       augment=False, warmup_iters=3)
+            step = lambda x: g(x, targets)
+        else:
+            sub = rng.choice(1200, 1024, False)
+            for _ in range(3):          # the 3 warm-up iterations (capture itself executes nothing), on batches[0] with the first subset
+                EF.finetune_step(pm, crit, opt, batches[0], targets, npoints=1024, max_norm=10.0, bf16=False, subset=sub,
+                                 augment=False)
+            step = lambda x: EF.finetune_step(pm, crit, opt, x, targets, npoints=1024, max_norm=10.0, bf16=False,
+                                              subset=rng.choice(1200, 1024, False), augment=False)
+        for x in batches:
+            losses.append(float(step(x)["loss"]))
+        return losses, {k: v.detach().clone() for k, v in pm.named_parameters()}
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    assert max(abs(a - b) for a, b in zip(le, lg)) <= 1e-5 * max(le)
+    assert max(rel(pg[k], pe[k]) for k in pe) <= 1e-5
