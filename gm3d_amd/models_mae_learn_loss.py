@@ -18,6 +18,8 @@ execution, not of results:
 """
 from functools import partial
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -67,6 +69,17 @@ def drop_path_scales(B, probs, training, device):
 
 
 _keep_cache = {}
+
+
+PARALLEL_DECODERS = os.environ.get("GM3D_PARALLEL_DECODERS", "0") == "1"
+_decoder_streams = {}
+
+
+def _decoder_stream(device):
+    key = (device.type, device.index)
+    if key not in _decoder_streams:
+        _decoder_streams[key] = torch.cuda.Stream(device=device)
+    return _decoder_streams[key]
 
 
 FUSED_STACK = True   # False: per-op PyTorch modules below (kept as the in-package cross-check of the fused path)
@@ -359,6 +372,18 @@ class MaskedAutoencoderViT(nn.Module):
         x_full = torch.cat([x_vis, mask_tokens], dim=1)
         pos_full = torch.cat([take(pos_all, vis_ids), take(pos_all, mask_ids)], dim=1)
 
+        # The two decoders are independent given x_full: each of their GEMMs (8192 rows) is at most one wave of tiles on
+        # 256 CUs, so the loss-prediction decoder runs on a second HIP stream beside the reconstruction decoder (forward
+        # here, backward by autograd on the same streams; a captured graph keeps the fork/join as parallel branches).
+        side = None
+        if PARALLEL_DECODERS and need_pix_pred and x_full.is_cuda:
+            main = torch.cuda.current_stream()
+            side = _decoder_stream(x_full.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
+            x_full.record_stream(side)
+            pos_full.record_stream(side)
         rebuild_points = None
         if need_pix_pred:
             x_rec = self.MAE_decoder(x_full, pos_full, N)
@@ -368,7 +393,11 @@ class MaskedAutoencoderViT(nn.Module):
                 rebuild_points = heads.LinearBiasFn.apply(x_rec, c.weight, c.bias, heads._adt())
             else:
                 rebuild_points = F.linear(x_rec, c.weight.squeeze(-1), c.bias)  # B L 96
-        loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+            loss_pred_.record_stream(torch.cuda.current_stream())
+        else:
+            loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
         return {
             "pix_pred": rebuild_points,
             "mask": mask,
