@@ -598,6 +598,40 @@ __global__ void pn1_bwd_finalize_kernel(const double* __restrict__ q, const doub
     dbeta[c] = (float)t1;
 }
 
+// ------------------------------------------------------------------ teacher-guided mask + visible / masked id lists
+// One wave per sample (L <= 64 tokens, lane = token).  generate_mask (P/models_mae_learn_loss.py:744-784): the
+// `len_loss` tokens with the highest predicted loss are always masked; the rest are ranked by `noise` and the first
+// `len_keep` stay visible.  Ranks are counted with v_readlane broadcasts ((value, index) order, so ties are
+// well-defined); the id lists are the visible / masked token indices in ascending order (= boolean-mask indexing order,
+// P/:298-299,649-650), written through ballot + popcount prefix positions.
+__global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict__ loss_pred, const float* __restrict__ noise,
+                                                         int L, int len_keep, int len_loss, float* __restrict__ mask,
+                                                         long long* __restrict__ vis_ids, long long* __restrict__ mask_ids) {
+    const int b = blockIdx.x, l = threadIdx.x;
+    const bool in = l < L;
+    const float lp = in ? loss_pred[(size_t)b * L + l] : 0.f;
+    float nz = in ? noise[(size_t)b * L + l] : 0.f;
+    int rank = 0;
+    for (int j = 0; j < L; ++j) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lp), j));
+        rank += (o < lp || (o == lp && j < l)) ? 1 : 0;
+    }
+    if (in && rank >= L - len_loss) nz = INFINITY;
+    int rank2 = 0;
+    for (int j = 0; j < L; ++j) {
+        const float o = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(nz), j));
+        rank2 += (o < nz || (o == nz && j < l)) ? 1 : 0;
+    }
+    const bool keep = in && rank2 < len_keep;
+    const unsigned long long kb = __ballot(keep), mb = __ballot(in && !keep);
+    const unsigned long long below = l == 0 ? 0ull : (~0ull >> (64 - l));
+    if (in) {
+        mask[(size_t)b * L + l] = keep ? 0.f : 1.f;
+        if (keep) vis_ids[(size_t)b * len_keep + __popcll(kb & below)] = l;
+        else mask_ids[(size_t)b * (L - len_keep) + __popcll(mb & below)] = l;
+    }
+}
+
 static inline bool chan_ok(int C) { return C >= 8 && C % 8 == 0 && C <= 1024; }
 static inline int threads_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; if (sl < 1) sl = 1; return sl * tpr; }
 static inline int slices_for(int C) { const int tpr = C / 8; int sl = 256 / tpr; return sl < 1 ? 1 : sl; }
@@ -894,6 +928,19 @@ extern "C" int gm3d_pn1_bwd_finalize(const double* q, const double* mcov, const 
     if (!q || !mcov || !w || !gamma || !rstd || !dw || !dgamma || !dbeta || C < 1) return GM3D_EINVAL;
     hipLaunchKernelGGL(pn1_bwd_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, q, mcov, w, gamma, rstd, dw,
                        dgamma, dbeta, C);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_mask_select(const float* loss_pred, const float* noise, int B, int L, int len_keep, int len_loss,
+                                float* mask, long long* vis_ids, long long* mask_ids, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!loss_pred || !noise || !mask || !vis_ids || !mask_ids || B < 0 || L < 1) return GM3D_EINVAL;
+    if (len_keep < 0 || len_loss < 0 || len_keep + len_loss > L) return GM3D_EINVAL;
+    if (L > 64) return GM3D_EUNSUPPORTED;
+    if (B == 0) return GM3D_OK;
+    hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, loss_pred, noise, L, len_keep, len_loss,
+                       mask, vis_ids, mask_ids);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -308,6 +308,17 @@ def _side_stream(device):
     return _side_streams[key]
 
 
+_arange_cache = {}
+
+
+def _arange_ids(B, L, device):
+    """(B,L) int64 rows of 0..L-1 (the all-visible id list of the teacher pass), cached per shape."""
+    key = (B, L, device.type, device.index)
+    if key not in _arange_cache:
+        _arange_cache[key] = torch.arange(L, device=device).unsqueeze(0).expand(B, L).contiguous()
+    return _arange_cache[key]
+
+
 def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None, mask_noise=None, augment=True,
                           aug_draws=None, optimizer=None):
     """First half of P/engine_pretrain.py:77-197: augment -> teacher -> mask -> student -> losses -> backward.
@@ -340,17 +351,25 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
                 tokens = raw.encoder(group[0])
                 pos_all = raw.embed_pos(group[1])
         with torch.no_grad():
-            outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False)
-            mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
-                                         total_epoch=args.epochs, noise=mask_noise)
+            all_ids = (_arange_ids(B, L, samples.device), _arange_ids(B, 0, samples.device))
+            outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False, ids=all_ids)
+            ids = None
+            if samples.is_cuda and L <= 64:       # mask + visible / masked id lists in one launch
+                mask, vis_ids, mask_ids = teacher.generate_mask_ids(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True,
+                                                                    epoch=epoch, total_epoch=args.epochs, noise=mask_noise)
+                ids = (vis_ids, mask_ids)
+            else:
+                mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
+                                             total_epoch=args.epochs, noise=mask_noise)
             bool_masked_pos = mask.flatten(1).to(torch.bool)
         if overlap:
             main.wait_stream(side)
             tokens.record_stream(main)
             pos_all.record_stream(main)
-        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens, pos_all=pos_all)
+        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens, pos_all=pos_all, ids=ids)
         M = outs["mask_num"]
-        loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"])
+        loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"],
+                                     mask_ids=ids[1] if ids is not None else None)
         loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
         loss = 13.889 * loss_mse + 1.0 * loss_chfr                      # P/:153
         loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos,

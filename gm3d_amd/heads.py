@@ -128,8 +128,8 @@ class LossPredHeadFn(torch.autograd.Function):
             a = torch.empty(R, C, dtype=adt, device=dev)
             _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
                     _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
-            W1 = w1.detach().reshape(w1.shape[0], C).float()
-            wv = W1.mean(dim=0)                                   # (C,) -- reduction over 384 rows per output: small
+            W1 = _c32(w1.reshape(w1.shape[0], C))
+            wv = colsum(W1, torch.float32) * (1.0 / w1.shape[0])   # (C,) mean over the 384 output rows, own two-stage sum
             out = (a @ wv.to(adt)).float() + b1.detach().float().mean()
             if meta["grad"] and any(ctx.needs_input_grad):
                 if not training:

@@ -348,7 +348,7 @@ class MaskedAutoencoderViT(nn.Module):
         return (F.linear(h, w.unsqueeze(0)).squeeze(-1) + c1.bias.mean()).view(B, L)
 
     def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True, tokens=None,
-                pos_all=None):
+                pos_all=None, ids=None):
         """pts (B,N,3) f32, mask (B,64) bool (True = masked).  Extra keyword-only conveniences for the
         engine: `num_visible` (static visible count, avoids a host sync), `group` (a previously
         computed (neighborhood, center, neighborhood_org), e.g. the teacher's -- the student sees the
@@ -356,7 +356,7 @@ class MaskedAutoencoderViT(nn.Module):
         teacher pass never reads, P/engine_pretrain.py:86-94), `tokens` / `pos_all` (this model's token embed and
         positional embed of all 64 groups when the engine has already evaluated them -- neither depends on the mask)."""
         neighborhood, center, neighborhood_org = group if group is not None else self.group_divider(pts)
-        vis_ids, mask_ids = split_ids(mask, num_visible)
+        vis_ids, mask_ids = ids if ids is not None else split_ids(mask, num_visible)   # ids: precomputed (generate_mask_ids)
         if pos_all is None:
             pos_all = self.embed_pos(center)
         x_vis = self._encode_visible(neighborhood, vis_ids, pos_all, tokens)
@@ -409,11 +409,12 @@ class MaskedAutoencoderViT(nn.Module):
             "center": center,
         }
 
-    def forward_loss(self, pred, target, mask):
+    def forward_loss(self, pred, target, mask, mask_ids=None):
         """pred (B,M,96) = pix_pred[:, -M:], target = neighborhood (B,64,32,3), mask (B,64) bool (P/:384-412)."""
         N, t, n, D = target.shape
         M = pred.shape[1]
-        _, mask_ids = split_ids(mask, t - M)
+        if mask_ids is None:
+            _, mask_ids = split_ids(mask, t - M)
         target = take(target, mask_ids).reshape(-1, n, D).to(torch.float32)
         pred = pred.reshape(-1, n, D).to(torch.float32)
         loss = self.loss_func(pred, target).reshape(N, -1, n)
@@ -437,6 +438,8 @@ class MaskedAutoencoderViT(nn.Module):
             noise = torch.rand(N, L, device=loss_pred.device)
         else:
             noise = noise.to(loss_pred.device, torch.float32).clone()
+        if loss_pred.is_cuda and L <= 64:
+            return self.generate_mask_ids(loss_pred, mask_ratio, guide, epoch, total_epoch, noise)[0]
         if len_loss > 0:
             forced = torch.argsort(loss_pred.float(), dim=1)[:, L - len_loss:]
             noise.scatter_(1, forced, float("inf"))
@@ -444,6 +447,27 @@ class MaskedAutoencoderViT(nn.Module):
         mask = torch.ones(N, L, device=loss_pred.device)
         mask.scatter_(1, keep, 0.0)
         return mask
+
+    @torch.no_grad()
+    def generate_mask_ids(self, loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None):
+        """generate_mask plus the id lists split_ids would derive from it, as ONE launch (gm3d_mask_select):
+        -> (mask (B,L) f32 0 keep / 1 remove, vis_ids (B,len_keep) int64, mask_ids (B,L-len_keep) int64)."""
+        from ._capi import lib
+        N, L = loss_pred.shape
+        len_keep = int(L * (1 - mask_ratio))
+        keep_ratio = float((epoch + 1) / total_epoch) * 0.5 if guide else 0.5
+        len_loss = int((L - len_keep) * keep_ratio)
+        dev = loss_pred.device
+        if noise is None:
+            noise = torch.rand(N, L, device=dev)
+        noise = noise.to(dev, torch.float32).contiguous()
+        lp = loss_pred.detach().float().contiguous()
+        mask = torch.empty(N, L, dtype=torch.float32, device=dev)
+        vis_ids = torch.empty(N, len_keep, dtype=torch.int64, device=dev)
+        mask_ids = torch.empty(N, L - len_keep, dtype=torch.int64, device=dev)
+        ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
+                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), ops._stream())
+        return mask, vis_ids, mask_ids
 
     def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False):
         """P/:786-815.  relative=True: pairwise ranking BCE over masked tokens."""

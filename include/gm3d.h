@@ -251,6 +251,12 @@ int gm3d_pn1_finalize(const double *mom9, double rows, const float *w, const flo
  * dw (C,3), dgamma (C), dbeta (C). */
 int gm3d_pn1_bwd_finalize(const double *q, const double *mcov, const float *w, const float *gamma, const float *rstd,
                           float *dw, float *dgamma, float *dbeta, int C, gm3d_stream_t stream);
+/* Teacher-guided mask (models_mae_learn_loss.py:744-784 generate_mask) and the visible / masked token id lists the
+ * boolean-mask indexing of :298-299,649-650 produces, in one launch.  loss_pred, noise (B,L) f32; the len_loss tokens of
+ * highest loss_pred are always masked, the others are ranked by noise ((value, index) order) and the first len_keep stay
+ * visible.  mask (B,L) f32: 0 keep / 1 remove; vis_ids (B,len_keep), mask_ids (B,L-len_keep) int64 ascending.  L <= 64. */
+int gm3d_mask_select(const float *loss_pred, const float *noise, int B, int L, int len_keep, int len_loss, float *mask,
+                     long long *vis_ids, long long *mask_ids, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

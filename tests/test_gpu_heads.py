@@ -93,3 +93,31 @@ def test_heads_match_modules(train):
         assert err(bo[k], ro[k]) <= 2 * err(mo[k], ro[k]) + 2e-2 * amax(ro[k]), k
     for k in rg:
         assert err(bg[k], rg[k]) <= 2 * err(mg[k], rg[k]) + 2e-2 * amax(rg[k]) + 1e-6 * gn, k
+
+
+@pytest.mark.parametrize("B,L,ratio,epoch", [(128, 64, 0.6, 200), (5, 64, 0.6, 0), (7, 64, 0.75, 399), (3, 40, 0.5, 100), (2, 64, 0.6, 200)])
+def test_mask_select_kernel(B, L, ratio, epoch):
+    """gm3d_mask_select against the argsort/scatter formulation of generate_mask (P/:744-784) and split_ids, including
+    ties in loss_pred and in the noise (resolved towards the lower index on both sides via stable sorts)."""
+    from gm3d_amd import models_mae_learn_loss as M
+    m = M.mae_vit_base_patch16_dec512d8b()
+    g = torch.Generator().manual_seed(B * 1000 + L)
+    lp = torch.randn(B, L, generator=g)
+    noise = torch.rand(B, L, generator=g)
+    if B == 2:                       # heavy ties
+        lp = (lp * 2).round() / 2
+        noise = (noise * 8).floor() / 8
+    len_keep = int(L * (1 - ratio))
+    len_loss = int((L - len_keep) * (float((epoch + 1) / 400) * 0.5))
+    nz = noise.clone()
+    if len_loss > 0:
+        forced = torch.argsort(lp, dim=1, stable=True)[:, L - len_loss:]
+        nz.scatter_(1, forced, float("inf"))
+    keep = torch.argsort(nz, dim=1, stable=True)[:, :len_keep]
+    want = torch.ones(B, L)
+    want.scatter_(1, keep, 0.0)
+    mask, vis, msk = m.generate_mask_ids(lp.cuda(), ratio, True, epoch, 400, noise.cuda())
+    assert torch.equal(mask.cpu(), want)
+    wv, wm = M.split_ids(want.bool(), len_keep)
+    assert torch.equal(vis.cpu(), wv) and torch.equal(msk.cpu(), wm)
+    assert torch.equal(m.generate_mask(lp.cuda(), ratio, epoch=epoch, total_epoch=400, noise=noise).cpu(), want)
