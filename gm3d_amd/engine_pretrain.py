@@ -429,8 +429,10 @@ class GraphedPretrainStep:
     where every such reduction is one of our own kernels; tests/test_gpu_graph.py compares replay against eager."""
 
     def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3, augment=True,
-                 inject_mask_noise=False, grad_sync=None):
-        """inject_mask_noise=True: the (B,L) ranking noise of generate_mask becomes a static input filled by the caller
+                 inject_mask_noise=False, grad_sync=None, fwd_bwd=None, extra=None):
+        """fwd_bwd / extra: another engine's forward+backward half with its extra keyword arguments (the published-run
+        variant passes its own step_forward_backward and the frozen teacher); default: this module's.
+        inject_mask_noise=True: the (B,L) ranking noise of generate_mask becomes a static input filled by the caller
         (deterministic replays for the tests); otherwise it is drawn inside the graph.
         grad_sync: data-parallel mode -- TWO graphs (forward+backward | clip+AdamW+EMA) with the bucketed RCCL
         all-reduce of the flat gradient buffers issued eagerly between them."""
@@ -439,14 +441,23 @@ class GraphedPretrainStep:
         self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
         self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
         self.grad_sync = grad_sync
-        kw = dict(augment=augment, mask_noise=self.static_noise, grad_sync=grad_sync)
+        kw = dict(augment=augment, mask_noise=self.static_noise, grad_sync=grad_sync, **(extra or {}))
+        fwd_bwd = fwd_bwd or step_forward_backward
         if grad_sync is not None:
             grad_sync.overlap = False
+
+        def whole(samples):
+            out = fwd_bwd(model, model_ema, samples, epoch, args, optimizer=optimizer, **kw)
+            if grad_sync is not None:
+                grad_sync.finish()
+            out["grad_norm"] = step_update(model, model_ema, optimizer)
+            return out
+
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup_iters):
-                pretrain_step(model, model_ema, optimizer, self.static_in.clone(), epoch, args, **kw)
+                whole(self.static_in.clone())
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
@@ -456,10 +467,10 @@ class GraphedPretrainStep:
         if grad_sync is None:
             self.graph2 = None
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
-                self.out = pretrain_step(model, model_ema, optimizer, self.static_in, epoch, args, **kw)
+                self.out = whole(self.static_in)
         else:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
-                self.out = step_forward_backward(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
+                self.out = fwd_bwd(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
             self.graph2 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)

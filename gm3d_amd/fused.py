@@ -41,7 +41,8 @@ class _WeightCache:
         self._pinned = {}      # data_ptr -> bf16 buffer
         self._groups = []      # (fp32 list, bf16 list)
 
-    def pin(self, model, dtype=torch.bfloat16):
+    def pin(self, model, dtype=torch.bfloat16, static=False):
+        """static=True: frozen weights -- cast once, never re-cast by refresh()."""
         src = [p for p in model.parameters() if p.dim() >= 2 and p.dtype == torch.float32 and p.is_cuda
                and not self._is_pinned(p)]
         if not src:
@@ -49,6 +50,10 @@ class _WeightCache:
         dst = [torch.empty_like(p, dtype=dtype) for p in src]
         for p, d in zip(src, dst):
             self._pinned[p.data_ptr()] = (d, weakref.ref(p))
+        if static:
+            with torch.no_grad():
+                torch._foreach_copy_(dst, [p.detach() for p in src])
+            return
         self._groups.append(([p.detach() for p in src], dst))
         with torch.no_grad():
             torch._foreach_copy_(dst, self._groups[-1][0])

@@ -1,0 +1,206 @@
+"""-m gpu: the published-run variant on the HIP kernels against (a) the fixture produced by the REFERENCE's
+own variant model + frozen Point_MAE + forward_features_Decoder and (b) the CPU oracle's iteration, in fp32; bf16 + hipGraph
+replay as a consistency band."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import model_ref as R
+from oracle import published_ref as PR
+from tests import clouds
+from tests.test_gpu_model import FeedDropPath, rel
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+TCFG = {"group_size": 32, "num_group": 64, "loss": "cdl2",
+        "transformer_config": {"mask_ratio": 0, "mask_type": "rand", "trans_dim": 384, "encoder_dims": 384, "depth": 12,
+                               "drop_path_rate": 0.1, "num_heads": 6, "decoder_depth": 4, "decoder_num_heads": 6}}
+
+
+@pytest.fixture(scope="module")
+def M():
+    from gm3d_amd import models_mae_learn_loss as M
+    return M
+
+
+def build(seed_s=11, seed_t=12, drop_path=None):
+    from gm3d_amd import models_mae_learn_loss_Classifier_SVM_feature_besed as V
+    from gm3d_amd.point_mae import Point_MAE
+    torch.manual_seed(0)
+    s = V.mae_vit_base_patch16_dec512d8b()
+    R.det_fill_(s, seed=seed_s)
+    t = Point_MAE(TCFG)
+    R.det_fill_(t, seed=seed_t)
+    if drop_path is not None:
+        from gm3d_amd import models_mae_learn_loss as MM
+        for mod in s.modules():
+            if isinstance(mod, MM.DropPath):
+                mod.drop_prob = drop_path
+    for p in t.parameters():
+        p.requires_grad_(False)
+    return s.cuda(), t.cuda().eval()
+
+
+def picked(g):
+    return g if g.numel() <= 20000 else g.flatten()[::7]
+
+
+def noise_from_shuffle(lp, len_loss, seed):
+    """Replay the reference's np.random.shuffle (P/:1092-1094) as a noise ranking for the device mask kernel."""
+    B, L = lp.shape
+    rng = np.random.RandomState(seed)
+    noise = torch.zeros(B, L)
+    order = torch.argsort(lp, dim=1)
+    for i in range(B):
+        rest = np.delete(np.arange(L), order[i, L - len_loss:].numpy())
+        rng.shuffle(rest)
+        noise[i, torch.from_numpy(rest)] = torch.arange(len(rest), dtype=torch.float32)
+    return noise
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_against_reference_fixture(M, fused, monkeypatch):
+    monkeypatch.setattr(M, "FUSED_STACK", fused)
+    fx = np.load(os.path.join(GOLD, "published_b4.npz"))
+    student, teacher = build()
+    pts = torch.from_numpy(fx["pts"]).cuda()
+    B = pts.shape[0]
+    student.eval()
+    with torch.no_grad():
+        t = student(pts.clone(), mask=torch.zeros(B, 64, dtype=torch.bool, device="cuda"))
+    for k in ("loss_pred", "features", "pix_pred"):
+        assert rel(t[k], fx["ema_" + k]) <= 1e-5, k
+    lp = torch.from_numpy(fx["ema_loss_pred"])
+    for epoch, after200 in ((0, False), (150, False), (299, False), (60, True)):
+        len_loss = int(39 * student.keep_ratio(True, epoch, 300, after200))
+        if len_loss <= 0:       # unguided: argsort of the recorded randn draw
+            noise = torch.from_numpy(fx["mask_noise_e%d" % epoch])
+        else:
+            noise = noise_from_shuffle(lp, len_loss, 7 + epoch)
+        m = student.generate_mask(lp.cuda(), 0.6, guide=True, epoch=epoch, total_epoch=300, after_200_epoch=after200, noise=noise)
+        assert np.array_equal(m.cpu().numpy(), fx["mask_e%d_%d" % (epoch, int(after200))]), (epoch, after200)
+    mask = torch.from_numpy(fx["mask_e150_0"]).bool().cuda()
+    student.train()
+    feed = FeedDropPath(fx["droppath_masks"])
+    monkeypatch.setattr(M, "drop_path", feed)
+    monkeypatch.setattr(M, "drop_path_scale", feed.scale)
+    s = student(pts.clone(), mask=mask)
+    assert feed.masks == []
+    Mn = s["mask_num"]
+    assert Mn == int(fx["mask_num"])
+    for k in ("features", "pix_pred", "loss_pred"):
+        assert rel(s[k], fx["student_" + k]) <= 1e-5, k
+    _, mask_ids = M.split_ids(mask, 64 - Mn)
+    ft, pt, pr = teacher.features_decoder(t["neighborhood"], t["center"], s["pix_pred"][:, -Mn:].detach(), mask_ids)
+    assert rel(ft, fx["feature_target"]) <= 1e-5 and rel(pt, fx["point_target"]) <= 1e-5 and rel(pr, fx["point_reconstructed"]) <= 1e-5
+    lo = student.forward_loss(s["pix_pred"][:, -Mn:], ft, s["mask"], pt, pr)
+    ll = student.forward_learning_loss(s["loss_pred"][:, -Mn:], mask, lo["matrix"].detach(), relative=True)
+    assert rel(lo["MSE_mean"], fx["mse_mean"]) <= 1e-5 and rel(lo["Chamfer_mean"], fx["chamfer_mean"]) <= 1e-5
+    assert rel(lo["matrix"], fx["matrix"]) <= 1e-5 and rel(ll, fx["loss_learn"]) <= 1e-5
+    (13.889 * lo["MSE_mean"] + 1000.0 * lo["Chamfer_mean"] + ll).backward()
+    named = dict(student.named_parameters())
+    assert sorted(k for k, p in named.items() if p.grad is None) == sorted(map(str, fx["no_grad_params"]))
+    gn = float(torch.sqrt(sum(p.grad.double().pow(2).sum() for p in named.values() if p.grad is not None)))
+    assert abs(gn - float(fx["grad_norm"])) <= 2e-5 * float(fx["grad_norm"])
+    for k in fx.files:
+        if k.startswith("grad/"):
+            g = named[k[5:]].grad
+            ref_n = float(fx["gradnorm/" + k[5:]])
+            assert abs(float(g.double().norm()) - ref_n) <= 5e-5 * ref_n + 1e-5 * gn, k
+            assert float((picked(g).double().cpu() - torch.from_numpy(fx[k]).double()).abs().max()) <= 5e-5 * ref_n + 1e-5 * gn, k
+
+
+def _args(**kw):
+    base = dict(mask_ratio=0.6, epochs=300, relative=True, bf16=False, accum_iter=1, after_epoch=15, loss_multiply_by=(13.889, 1000.0),
+                after_200_epoch=False, shared_learnable_tokens=False, learning_loss=True, lr=1e-3, min_lr=0.0, warmup_epochs=10)
+    base.update(kw)
+    return SimpleNamespace(**base)
+
+
+@pytest.mark.parametrize("epoch", [150, 3])
+def test_step_against_oracle(M, epoch):
+    """One whole iteration (EMA teacher -> mask -> student -> frozen teacher -> losses -> clip -> AdamW -> EMA), product on the
+    GPU vs oracle on the CPU; DropPath off; the mask permutation shared through a noise ranking.  epoch 3 < after_epoch uses
+    the plain loss sum, epoch 150 the 13.889 / 1000 weights."""
+    from gm3d_amd import engine_pretrain_Classifier_SVM as EV
+    torch.manual_seed(0)
+    om = R.det_fill_(PR.PublishedGM3D(drop_path_rate=0.0), seed=21)
+    ot = R.det_fill_(PR.FrozenPointMAE(), seed=22).eval()
+    pm, pt = build(21, 22, drop_path=0.0)
+    om.train(); pm.train()
+    oema, pema = R.ModelEma(om, decay=0.999), EV.ModelEma(pm, decay=0.999)
+    oopt = torch.optim.AdamW(R.param_groups(om, 0.05), lr=1e-3)
+    popt = EV.build_optimizer(pm, lr=1e-3, weight_decay=0.05)
+    x = clouds.gaussian(4, 1024, seed=91)
+    noise = torch.rand(4, 64, generator=torch.Generator().manual_seed(13))
+
+    class _NoiseRng:
+        def __init__(self, noise):
+            self.noise, self.i = noise, 0
+
+        def shuffle(self, arr):
+            n = self.noise[self.i][torch.from_numpy(arr)]
+            arr[:] = arr[torch.argsort(n).numpy()]
+            self.i += 1
+
+    ores = PR.pretrain_step(om, oema, ot, oopt, x.clone(), epoch=epoch, total_epoch=300, mask_rng=_NoiseRng(noise),
+                            mask_noise=noise)     # epoch 3: no forced tokens, the unguided branch ranks by the same noise
+    pres = EV.pretrain_step(pm, pema, pt, popt, x.clone().cuda(), epoch, _args(), mask_noise=noise, augment=False)
+    assert torch.equal(pres["mask"].cpu(), ores["mask"])
+    assert rel(pres["loss_mse"], ores["mse"]) <= 1e-5 and rel(pres["loss_chfr"], ores["chamfer"]) <= 1e-5
+    assert rel(pres["loss"], ores["loss"]) <= 1e-5 and rel(pres["loss_learn"], ores["loss_learn"]) <= 1e-5
+    assert rel(pres["matrix"], ores["matrix"]) <= 1e-5
+    assert rel(pres["grad_norm"], ores["grad_norm"]) <= 5e-5
+    og = dict(om.named_parameters())
+    gn = float(ores["grad_norm"])
+    clip = min(1.0, 5.0 / (gn + 1e-6))
+    for k, p in pm.named_parameters():
+        if og[k].grad is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert float((p.grad.double().cpu() - og[k].grad.double()).abs().max()) <= 2e-4 * float(og[k].grad.abs().max()) + 1e-5 * gn * clip, k
+    # EMA of the BatchNorm buffers and parameters moved towards the student
+    for (k, a), (_, b) in zip(oema.ema.state_dict().items(), pema.ema.state_dict().items()):
+        if a.dtype.is_floating_point and "running" in k:
+            assert rel(b, a, floor=1e-6) <= 1e-4, k
+
+
+def test_bf16_graph_replay_matches_eager(M):
+    """bf16 iteration with the flat optimizer: hipGraph replay == eager on identical inputs (mask noise injected; DropPath and
+    augmentation off), and the loss falls over a few steps."""
+    from gm3d_amd import engine_pretrain_Classifier_SVM as EV
+    x = [clouds.gaussian(8, 1024, seed=300 + i).cuda() for i in range(3)]
+    noise = [torch.rand(8, 64, generator=torch.Generator().manual_seed(40 + i)).cuda() for i in range(3)]
+    args = _args(bf16=True)
+
+    # common state: build once, snapshot, run eager; restore, run graph
+    pm, pt = build(31, 32, drop_path=0.0)
+    pm.train()
+    ema = EV.ModelEma(pm, decay=0.999)
+    opt = EV.build_optimizer(pm, lr=1e-3, weight_decay=0.05, flat=True, model_ema=ema)
+    g = EV.graphed_step(pm, ema, pt, opt, args, x[0], 150, augment=False, inject_mask_noise=True, warmup_iters=2)
+    state = ({k: v.clone() for k, v in pm.state_dict().items()}, {k: v.clone() for k, v in ema.ema.state_dict().items()},
+             opt.M.clone(), opt.V.clone(), opt.step_dev.clone())
+
+    def restore():
+        with torch.no_grad():
+            pm.load_state_dict(state[0]); ema.ema.load_state_dict(state[1])
+            opt.M.copy_(state[2]); opt.V.copy_(state[3]); opt.step_dev.copy_(state[4])
+            opt.sync_shadows()
+
+    restore()
+    le = []
+    for xi, ni in zip(x, noise):
+        o = EV.pretrain_step(pm, ema, pt, opt, xi.clone(), 150, args, mask_noise=ni, augment=False)
+        le.append(float(o["loss"] + o["loss_learn"]))
+    pe = {k: v.clone() for k, v in pm.state_dict().items()}
+    restore()
+    lg = []
+    for xi, ni in zip(x, noise):
+        o = g(xi, mask_noise=ni)
+        lg.append(float(o["loss"] + o["loss_learn"]))
+    assert all(np.isfinite(le)) and max(abs(a - b) for a, b in zip(le, lg)) <= 2e-3 * max(abs(v) for v in le)
+    assert max(rel(pm.state_dict()[k], pe[k], floor=1e-3) for k in pe if pe[k].dtype.is_floating_point) <= 2e-2
