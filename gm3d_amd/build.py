@@ -24,6 +24,7 @@ SOURCES = {
     "rowops.hip": [],
     "embed.hip": [],
     "optim.hip": [],
+    "gemm.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,32 @@
+"""bf16 GEMM of the block / mini-PointNet shapes on the hand-written MFMA kernel (csrc/gemm.hip): y = x @ w^T (+ bias).
+
+Status (round 1, tools/gemm_kbench.py on MI355X): correct (tests/test_gpu_gemm.py) but NOT yet faster than the tuned hipBLASLt
+solutions the step uses -- 0.43x..1.10x across the step's 18 shapes (340-520 TFLOP/s on the large ones vs 430-700): the
+128x128 tile with a 2-deep register-prefetch pipeline is bound by global-load latency (64 KB in flight per CU).  It is therefore
+not wired into the model; the next step is a 256x128 tile with a 3-4 deep direct-to-LDS pipeline, then the bias/GELU/residual
+epilogues that are the real reason to own this kernel."""
+import torch
+
+from ._capi import lib
+from .ops import _launch, _ptr, _stream
+
+ENABLED = True
+
+
+def supported(x, w):
+    """x (M,K) bf16 with unit inner stride, w (N,K) bf16 contiguous rows; N % 128 == 0, K % 64 == 0."""
+    return (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
+            and x.shape[1] == w.shape[1] and w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0 and x.stride(1) == 1
+            and w.stride(1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.stride(0) >= x.shape[1]
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
+def linear_tn(x, w, bias=None, out=None):
+    """x (M,K) bf16, w (N,K) bf16, bias (N) f32 or None -> (M,N) bf16 = x @ w^T + bias (fp32 accumulate, one rounding)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K,
+            x.stride(0), w.stride(0), out.stride(0), _stream())
+    return out

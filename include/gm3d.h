@@ -257,6 +257,11 @@ int gm3d_pn1_bwd_finalize(const double *q, const double *mcov, const float *w, c
  * visible.  mask (B,L) f32: 0 keep / 1 remove; vis_ids (B,len_keep), mask_ids (B,L-len_keep) int64 ascending.  L <= 64. */
 int gm3d_mask_select(const float *loss_pred, const float *noise, int B, int L, int len_keep, int len_loss, float *mask,
                      long long *vis_ids, long long *mask_ids, gm3d_stream_t stream);
+/* C (M,N) bf16 = A (M,K) bf16 . W (N,K)^T bf16 (+ bias (N) f32), fp32 accumulation: nn.Linear / Conv1d(k=1) forward with W the
+ * weight as stored, input gradient with W the transposed weight.  Row pitches lda / ldw / ldc in elements (multiples of 8).
+ * Limits: N % 128 == 0, K % 64 == 0. */
+int gm3d_gemm_tn_bf16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw,
+                      int ldc, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

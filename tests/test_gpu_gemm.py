@@ -1,0 +1,42 @@
+"""-m gpu: the hand-written bf16 MFMA GEMM (gm3d_gemm_tn_bf16) against an fp32 matmul of the same bf16 operands.
+Tolerance: one bf16 rounding of the result (2^-8 relative) plus fp32 accumulation-order noise."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 384, 1152), (3200, 1536, 384), (8192, 384, 1536), (3200, 384, 384), (100, 64, 128),
+                                   (129, 128, 256), (4096, 512, 384), (1, 1152, 384)])
+@pytest.mark.parametrize("bias", [False, True])
+def test_gemm_tn(M, K, N, bias):
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) if bias else None
+    assert gemm.supported(x, w)
+    y = gemm.linear_tn(x, w, b)
+    ref = x.float() @ w.float().t()
+    if bias:
+        ref = ref + b
+    err = (y.float() - ref).abs()
+    assert float((err / (ref.abs() + 1.0)).max()) <= 6e-3
+    assert float(err.mean()) <= 3e-3 * float(ref.abs().mean())
+    assert torch.equal(y, ref.bfloat16()) or float((y.float() - ref.bfloat16().float()).abs().max()) <= 2.0 ** -6 * float(ref.abs().max())
+
+
+def test_gemm_strided_operands_and_limits():
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib
+    big = torch.randn(500, 1152, device="cuda").bfloat16()
+    x = big[:, 384:768]                                    # row pitch 1152, K = 384
+    w = (torch.randn(256, 384, device="cuda") / 20).bfloat16()
+    assert gemm.supported(x, w)
+    y = gemm.linear_tn(x, w)
+    assert float((y.float() - x.float() @ w.float().t()).abs().max()) <= 0.05
+    out = torch.zeros(500, 512, device="cuda", dtype=torch.bfloat16)
+    gemm.linear_tn(x, w, out=out[:, 256:])                 # strided output
+    assert torch.equal(out[:, 256:], y) and float(out[:, :256].abs().max()) == 0.0
+    assert not gemm.supported(x, w[:100])                  # N % 128
+    assert lib.gm3d_gemm_tn_bf16(1, 1, None, 1, 8, 100, 64, 64, 64, 100, None) == -2
