@@ -23,40 +23,55 @@ constexpr int GPITCH = 72;                     // bf16 elements per LDS row (64 
 constexpr int GCP = 132;                       // floats per row of the fp32 epilogue tile
 constexpr int GSTAGE = (GBM + GBN) * GPITCH;   // bf16 elements per stage
 
+template <int KTT>   // K / 64 when it is one of the path's values (fully unrolled: exact s_waitcnt counts), 0 = run-time loop
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ C, int M,
-                                                              int N, int K, int lda, int ldw, int ldc, int tiles_n) {
+                                                              int N, int K, int lda, int ldw, int ldc, int tiles_n,
+                                                              int total_tiles, bf16_t* __restrict__ G, int ldg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(gsm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    // consecutive workgroups share the A rows (same tile_m, all tile_n) so the activation tile is read once from HBM
-    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    // XCD-aware tile order: the hardware deals workgroups round-robin over the 8 XCDs (each with its own L2), so workgroup b
+    // takes logical tile (b % 8) * per_xcd + b / 8 -- every XCD walks a contiguous run of tiles in (tile_m, tile_n) order and
+    // the tiles_n workgroups that share one block of A rows hit the same L2 (A comes from HBM once, not tiles_n times).
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total_tiles) return;
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
     const int m0 = tile_m * GBM, n0 = tile_n * GBN;
     const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
 
-    // global -> register prefetch: 4 chunks of A and 4 of W per thread per stage (16 bytes each)
-    gbf16x8 pa[4], pw[4];
+    // global -> register prefetch, TWO stages deep: 4 chunks of A and 4 of W per thread per stage (16 bytes each), two register
+    // sets.  Iteration kt issues the loads of stage kt+2, multiplies stage kt, and only then parks stage kt+1 (issued one
+    // iteration ago) in the LDS buffer that stage kt-1 vacated: a load has a whole iteration plus a multiply to arrive.
+    gbf16x8 pa[2][4], pw[2][4];
     const int crow = tid >> 3, ckc = (tid & 7) * 8;           // chunk c = tid + 256*i -> row = crow + 32*i, k offset ckc
-    auto load_stage = [&](int k0) {
+    size_t aoff[4], woff[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = crow + 32 * i;
-            const int am = m0 + row;
-            pa[i] = am < M ? *reinterpret_cast<const gbf16x8*>(A + (size_t)am * lda + k0 + ckc) : gbf16x8{};
-            pw[i] = *reinterpret_cast<const gbf16x8*>(W + (size_t)(n0 + row) * ldw + k0 + ckc);
-        }
-    };
-    auto store_stage = [&](int st) {
-        bf16_t* as = sm + st * GSTAGE;
-        bf16_t* ws = as + GBM * GPITCH;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = crow + 32 * i;
-            *reinterpret_cast<gbf16x8*>(as + row * GPITCH + ckc) = pa[i];
-            *reinterpret_cast<gbf16x8*>(ws + row * GPITCH + ckc) = pw[i];
-        }
-    };
+    for (int i = 0; i < 4; ++i) {
+        const int row = crow + 32 * i;
+        // rows past M are clamped, not predicated: a branch per load makes the compiler serialise the loads behind
+        // s_waitcnt at every join; the clamped rows only feed output rows the epilogue never stores
+        const int am = m0 + row < M ? m0 + row : M - 1;
+        aoff[i] = (size_t)am * lda + ckc;
+        woff[i] = (size_t)(n0 + row) * ldw + ckc;
+    }
+#define GM3D_LOAD_STAGE(SET, K0)                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
+        pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));               \
+        pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + (K0));               \
+    }
+#define GM3D_STORE_STAGE(SET, ST)                                                         \
+    {                                                                                     \
+        bf16_t* as_ = sm + (ST) * GSTAGE;                                                 \
+        bf16_t* ws_ = as_ + GBM * GPITCH;                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                   \
+            const int row = crow + 32 * i;                                                \
+            *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i];           \
+            *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];           \
+        }                                                                                 \
+    }
 
     gf32x16 acc[2][2];
 #pragma unroll
@@ -66,31 +81,46 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-    const int KT = K / GBK;
-    load_stage(0);
-    store_stage(0);
+    const int KT = KTT > 0 ? KTT : K / GBK;
+    GM3D_LOAD_STAGE(0, 0)
+    if (KT > 1) GM3D_LOAD_STAGE(1, GBK)
+    GM3D_STORE_STAGE(0, 0)
     __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) load_stage((kt + 1) * GBK);
-        const bf16_t* as = sm + (kt & 1) * GSTAGE;
-        const bf16_t* ws = as + GBM * GPITCH;
+    // the loop is unrolled by two so that register-set indices are compile-time constants; with a compile-time KT it is
+    // fully unrolled, which lets the compiler count outstanding loads exactly (vmcnt(8): stage kt+2 stays in flight while
+    // stage kt+1 is parked) instead of draining them at every loop back-edge
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int ko = 16 * s + 8 * hh;
-            gbf16x8 fa[2], fw[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) fa[i] = *reinterpret_cast<const gbf16x8*>(as + (wm + 32 * i + r) * GPITCH + ko);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) fw[j] = *reinterpret_cast<const gbf16x8*>(ws + (wn + 32 * j + r) * GPITCH + ko);
-            // transposed product: rows (registers) = n, columns (lanes) = m
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < KT) store_stage((kt + 1) & 1);
-        __syncthreads();
+    for (int kt = 0; kt < (KTT > 0 ? KTT : KT); kt += 2) {
+#define GM3D_ITER(KT_, CUR, NXT)                                                                                           \
+    if ((KT_) < KT) {                                                                                                      \
+        if ((KT_) + 2 < KT) GM3D_LOAD_STAGE(CUR, ((KT_) + 2) * GBK) /* stage KT_+2 reuses register set CUR */              \
+        const bf16_t* as = sm + (CUR) * GSTAGE;                                                                            \
+        const bf16_t* ws = as + GBM * GPITCH;                                                                              \
+        /* all 16 operand fragments of the stage are requested from LDS before the first MFMA: one LDS round trip per */   \
+        /* stage on the critical path instead of one per k-step (the compiler then drains lgkmcnt progressively)       */   \
+        gbf16x8 fa[4][2], fw[4][2];                                                                                        \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                    \
+            const int ko = 16 * s + 8 * hh;                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+                fa[s][i] = *reinterpret_cast<const gbf16x8*>(as + (wm + 32 * i + r) * GPITCH + ko);                        \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
+                fw[s][j] = *reinterpret_cast<const gbf16x8*>(ws + (wn + 32 * j + r) * GPITCH + ko);                        \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);   /* keep the scheduler from sinking the reads back between the MFMAs */        \
+        /* transposed product: rows (registers) = n, columns (lanes) = m */                                                \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+                _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j], fa[s][i], acc[i][j], 0, 0, 0);           \
+        if ((KT_) + 1 < KT) GM3D_STORE_STAGE(NXT, NXT)          /* stage KT_+1 (register set NXT) -> LDS buffer NXT */     \
+        __syncthreads();                                                                                                   \
     }
+        GM3D_ITER(kt, 0, 1)
+        GM3D_ITER(kt + 1, 1, 0)
+    }
+#undef GM3D_ITER
+#undef GM3D_LOAD_STAGE
+#undef GM3D_STORE_STAGE
 
     // epilogue: acc -> fp32 tile in LDS (row = m, 4 consecutive n per register quad) -> + bias -> bf16, 16-byte stores
     float* cs = reinterpret_cast<float*>(gsm);
@@ -113,35 +143,81 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
             float v[8];
             const float4 x = *reinterpret_cast<const float4*>(cs + row * GCP + nc), y = *reinterpret_cast<const float4*>(cs + row * GCP + nc + 4);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+            float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (bias) {
                 const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + nc), b1 = *reinterpret_cast<const float4*>(bias + n0 + nc + 4);
-                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
             }
-            V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+            if (G) {
+                // fc1 epilogue: C (optional) = the pre-activation WITHOUT bias, rounded to bf16 -- what the GELU backward
+                // re-reads; G = GELU(bf16(f) + bias), from the rounded value so forward and backward see the same f
+                if (C) V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = gelu_f<bf16_t>((float)(bf16_t)v[e] + bv[e]);
+                V8<bf16_t>::store(G + (size_t)(m0 + row) * ldg + n0 + nc, v);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+            }
         }
     }
 }
 
 }  // namespace gm3d
 
-extern "C" int gm3d_gemm_tn_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
-                                 int ldw, int ldc, gm3d_stream_t stream) {
+static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
+                       void* G, int ldg, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!A || !W || !C || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
-    if (N % GBN || K % GBK || lda % 8 || ldw % 8 || ldc % 8 || lda < K || ldw < K || ldc < N) return GM3D_EUNSUPPORTED;
+    if (!A || !W || (!C && !G) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
+    if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
     const int tiles_m = (M + GBM - 1) / GBM, tiles_n = N / GBN;
     if ((long long)tiles_m * tiles_n > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
     const size_t lds_ab = (size_t)2 * GSTAGE * sizeof(bf16_t), lds_c = (size_t)GBM * GCP * sizeof(float);
     const size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GM3D_ELAUNCH;
-        attr_done = true;
+    const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
+#define GM3D_GEMM_CASE(KTT)                                                                                                   \
+    case KTT: {                                                                                                               \
+        static bool attr_done = false;                                                                                        \
+        if (!attr_done) {                                                                                                     \
+            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                                    (int)lds) != hipSuccess)                                                                  \
+                return GM3D_ELAUNCH;                                                                                          \
+            attr_done = true;                                                                                                 \
+        }                                                                                                                     \
+        hipLaunchKernelGGL(gemm_tn_bf16_kernel<KTT>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,       \
+                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg);      \
+        break;                                                                                                                \
     }
-    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3(tiles_m * tiles_n), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,
-                       (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n);
+    switch (K / GBK) {
+        GM3D_GEMM_CASE(2) GM3D_GEMM_CASE(4) GM3D_GEMM_CASE(6) GM3D_GEMM_CASE(8) GM3D_GEMM_CASE(16) GM3D_GEMM_CASE(18)
+        GM3D_GEMM_CASE(24)
+        default: {
+            static bool attr_done = false;
+            if (!attr_done) {
+                if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return GM3D_ELAUNCH;
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(gemm_tn_bf16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,
+                               (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg);
+        }
+    }
+#undef GM3D_GEMM_CASE
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
+}
+
+extern "C" int gm3d_gemm_tn_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda,
+                                 int ldw, int ldc, gm3d_stream_t stream) {
+    if (!C) return GM3D_EINVAL;
+    return gemm_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, 0, stream);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_gelu(const void* A, const void* W, const float* bias, void* F, void* G, int M, int N, int K,
+                                      int lda, int ldw, int ldf, int ldg, gm3d_stream_t stream) {
+    if (!G || !bias) return GM3D_EINVAL;
+    return gemm_launch(A, W, bias, F, M, N, K, lda, ldw, ldf, G, ldg, stream);
 }

@@ -270,23 +270,6 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restr
     }
 }
 
-// erf for the bf16 path: Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below bf16's 4e-3 resolution) costs one
-// rcp + one exp + 5 FMAs, about half of libm's erff; the GELU passes are VALU-bound on it (12.6 M elements per call).
-// The f32 (parity) path keeps libm's erff.
-template <class T> __device__ __forceinline__ float erf_t(float x);
-template <> __device__ __forceinline__ float erf_t<float>(float x) { return erff(x); }
-template <> __device__ __forceinline__ float erf_t<bf16_t>(float x) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * ax);
-    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-    const float r = 1.0f - poly * __expf(-ax * ax);
-    return copysignf(r, x);
-}
-template <class T> __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_t<T>(x * 0.70710678118654752440f)); }
-template <class T> __device__ __forceinline__ float gelu_grad_f(float x) {
-    return 0.5f * (1.0f + erf_t<T>(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
-}
-
 // g = GELU(f + bias), exact erf form (nn.GELU default).  C % 8 == 0.  blockDim.x = C/8: thread t owns columns
 // 8t..8t+7 (bias in registers) of every row the block visits, two rows (2 x 16 B per lane) in flight.
 template <class T>

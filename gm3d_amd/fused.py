@@ -20,6 +20,7 @@ import torch
 
 from . import _capi
 from ._capi import lib
+from . import gemm
 from .ops import _launch, _ptr, _stream, _DT
 
 LNC = 384
@@ -204,6 +205,13 @@ def block_params(block):
             block.mlp.fc2.bias]
 
 
+def _mm(x, w):
+    """x (R,K) @ w (N,K)^T: the hand-written MFMA kernel on the shapes where it beats the tuned library solution."""
+    if gemm.supported(x, w) and gemm.prefer_own(x.shape[0], w.shape[0], w.shape[1]):
+        return gemm.linear_tn(x, w)
+    return x @ w.t()
+
+
 class TransformerStackFn(torch.autograd.Function):
     """args: x (B,T,C), pos (B,T,C), meta, final_w, final_b, then PER_BLOCK tensors per block.
     meta: dict(num_heads, scale, eps, final_eps, adt, dp=[(scale_attn|None, scale_mlp|None) per block])."""
@@ -235,12 +243,18 @@ class TransformerStackFn(torch.autograd.Function):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             dp1, dp2 = meta["dp"][i]
             u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
-            qkv = h1 @ weight_cache.get(wqkv, adt).t()
+            qkv = _mm(h1, weight_cache.get(wqkv, adt))
             a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
-            p = a @ weight_cache.get(wproj, adt).t()
+            p = _mm(a, weight_cache.get(wproj, adt))
             x1, h2, m2, r2 = residual_ln_fwd(u, p, bproj, dp1, T, None, ln2w, ln2b, eps, adt, R, h=H2[i] if need else None)
-            f = h2 @ weight_cache.get(w1, adt).t()
-            g = bias_gelu_fwd(f, b1, adt, g=GG[i] if need else None)
+            W1 = weight_cache.get(w1, adt)
+            if gemm.FUSE_GELU and gemm.supported(h2, W1):
+                # fc1 + bias + GELU in the GEMM epilogue; the pre-activation is only written when a backward follows
+                f, g = gemm.linear_gelu(h2, W1, b1, f_out=torch.empty(R, W1.shape[0], dtype=adt, device=dev) if need else None,
+                                        g_out=GG[i] if need else None)
+            else:
+                f = h2 @ W1.t()
+                g = bias_gelu_fwd(f, b1, adt, g=GG[i] if need else None)
             o = g @ weight_cache.get(w2, adt).t()
             if need:
                 saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]

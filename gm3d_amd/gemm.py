@@ -11,6 +11,7 @@ from ._capi import lib
 from .ops import _launch, _ptr, _stream
 
 ENABLED = True
+FUSE_GELU = True      # fc1 + bias + GELU as one launch in the fused transformer stack
 
 
 def supported(x, w):
@@ -30,3 +31,21 @@ def linear_tn(x, w, bias=None, out=None):
     _launch("gm3d_gemm_tn_bf16", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K,
             x.stride(0), w.stride(0), out.stride(0), _stream())
     return out
+
+
+def linear_gelu(x, w, bias, f_out=None, g_out=None):
+    """fc1 -> GELU with the activation in the GEMM epilogue: g = GELU(x @ w^T + bias); `f_out` (optional) receives the
+    bf16 pre-activation WITHOUT bias (what bias_gelu_bwd re-reads).  -> (f_out | None, g)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if g_out is None:
+        g_out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_gelu", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_gelu, _ptr(x), _ptr(w), _ptr(bias),
+            _ptr(f_out), _ptr(g_out), M, N, K, x.stride(0), w.stride(0), f_out.stride(0) if f_out is not None else 0,
+            g_out.stride(0), _stream())
+    return f_out, g_out
+
+
+def prefer_own(M, N, K):
+    """Shapes where the hand-written kernel beats the tuned hipBLASLt solution on MI355X (tools/gemm_kbench.py)."""
+    return (N, K) == (384, 384) or ((N, K) == (1152, 384) and M <= 4096) or ((N, K) == (128, 256) and M >= 65536)

@@ -262,6 +262,11 @@ int gm3d_mask_select(const float *loss_pred, const float *noise, int B, int L, i
  * Limits: N % 128 == 0, K % 64 == 0. */
 int gm3d_gemm_tn_bf16(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw,
                       int ldc, gm3d_stream_t stream);
+/* fc1 + bias + exact-erf GELU in the GEMM epilogue (timm Mlp: fc1 -> GELU, Point_MAE.py:92-94):
+ * F (M,N) bf16 = A . W^T (no bias; optional, NULL when no backward will follow), G (M,N) bf16 = GELU(F + bias).
+ * Same operand rules and limits as gm3d_gemm_tn_bf16. */
+int gm3d_gemm_tn_bf16_gelu(const void *A, const void *W, const float *bias, void *F, void *G, int M, int N, int K, int lda,
+                           int ldw, int ldf, int ldg, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -40,3 +40,24 @@ def test_gemm_strided_operands_and_limits():
     assert torch.equal(out[:, 256:], y) and float(out[:, :256].abs().max()) == 0.0
     assert not gemm.supported(x, w[:100])                  # N % 128
     assert lib.gm3d_gemm_tn_bf16(1, 1, None, 1, 8, 100, 64, 64, 64, 100, None) == -2
+
+
+@pytest.mark.parametrize("M,with_f", [(8192, True), (3200, False), (77, True)])
+def test_gemm_gelu_epilogue(M, with_f):
+    """fc1 + bias + GELU fused: F = bf16(x @ w^T) (no bias), G = GELU(F + bias) -- equal to the two-kernel path
+    (library GEMM, then gm3d_bias_gelu_fwd) up to the GEMMs' accumulation order."""
+    from gm3d_amd import gemm, fused
+    K, N = 384, 1536
+    g = torch.Generator(device="cuda").manual_seed(M)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) * 0.3
+    f_out = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if with_f else None
+    f, gg = gemm.linear_gelu(x, w, b, f_out=f_out)
+    fref = (x.float() @ w.float().t())
+    if with_f:
+        assert float((f.float() - fref).abs().max()) <= 2.0 ** -7 * float(fref.abs().max())
+        two = fused.bias_gelu_fwd(f, b, torch.bfloat16)            # same f -> must agree to the last bit
+        assert torch.equal(two, gg)
+    gref = torch.nn.functional.gelu(fref.bfloat16().float() + b)
+    assert float((gg.float() - gref).abs().max()) <= 2.0 ** -6 * float(gref.abs().max()) + 1e-3
