@@ -27,7 +27,9 @@ template <int KTT>   // K / 64 when it is one of the path's values (fully unroll
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ C, int M,
                                                               int N, int K, int lda, int ldw, int ldc, int tiles_n,
-                                                              int total_tiles, bf16_t* __restrict__ G, int ldg) {
+                                                              int total_tiles, bf16_t* __restrict__ G, int ldg,
+                                                              bf16_t* __restrict__ P, uint8_t* __restrict__ ARG, int ldp,
+                                                              int bias_after_pool) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(gsm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -135,6 +137,31 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             }
     __syncthreads();
+    if (P) {
+        // max-pool epilogue (mini-PointNet: max over the 32 points of a group, models_mae_learn_loss.py:893,897): the tile
+        // holds 4 whole groups; thread = one column of two groups.  Values are rounded to bf16 BEFORE the comparison (first
+        // maximum wins), which reproduces the separate GEMM -> gm3d_group_max_fwd path decision for decision.
+        const int c = tid & 127, gh = tid >> 7;
+        const float b = bias ? bias[n0 + c] : 0.f;
+        const float pre = bias_after_pool ? 0.f : b, post = bias_after_pool ? b : 0.f;
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+            const int rowbase = (gh * 2 + gi) * 32;
+            if (m0 + rowbase < M) {
+                float best = -INFINITY;
+                int bk = 0;
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const float v = (float)(bf16_t)(cs[(rowbase + k) * GCP + c] + pre);
+                    if (v > best) { best = v; bk = k; }
+                }
+                const size_t o = (size_t)((m0 + rowbase) >> 5) * ldp + n0 + c;
+                P[o] = (bf16_t)(best + post);
+                ARG[o] = (uint8_t)bk;
+            }
+        }
+        if (!C) return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i;                 // 128 rows x 16 chunks of 8 columns
@@ -167,9 +194,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
 }  // namespace gm3d
 
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
-                       void* G, int ldg, gm3d_stream_t stream) {
+                       void* G, int ldg, gm3d_stream_t stream, void* P = nullptr, uint8_t* ARG = nullptr, int ldp = 0,
+                       int bias_after_pool = 0) {
     using namespace gm3d;
-    if (!A || !W || (!C && !G) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (!A || !W || (!C && !G && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (P && (!ARG || M % 32 || ldp < N)) return GM3D_EINVAL;
     if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
     if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
@@ -188,7 +217,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
             attr_done = true;                                                                                                 \
         }                                                                                                                     \
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<KTT>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,       \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg);      \
+                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,      \
+                           (bf16_t*)P, ARG, ldp, bias_after_pool);                                                           \
         break;                                                                                                                \
     }
     switch (K / GBK) {
@@ -202,7 +232,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
                 attr_done = true;
             }
             hipLaunchKernelGGL(gemm_tn_bf16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,
-                               (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg);
+                               (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,
+                               (bf16_t*)P, ARG, ldp, bias_after_pool);
         }
     }
 #undef GM3D_GEMM_CASE
@@ -220,4 +251,10 @@ extern "C" int gm3d_gemm_tn_bf16_gelu(const void* A, const void* W, const float*
                                       int lda, int ldw, int ldf, int ldg, gm3d_stream_t stream) {
     if (!G || !bias) return GM3D_EINVAL;
     return gemm_launch(A, W, bias, F, M, N, K, lda, ldw, ldf, G, ldg, stream);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_pool(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* arg, int M, int N,
+                                      int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream) {
+    if (!P || !arg) return GM3D_EINVAL;
+    return gemm_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, 0, stream, P, arg, ldp, bias_after_pool);
 }

@@ -15,6 +15,7 @@ import torch
 
 from ._capi import lib
 from .fused import weight_cache, LNC  # noqa: F401
+from . import gemm
 from .ops import _launch, _ptr, _stream, _DT
 
 SPLITK = 64  # row chunks of the weight-gradient GEMMs (K = 262,144 rows would otherwise run on a handful of CUs)
@@ -106,11 +107,15 @@ class EmbedFn(torch.autograd.Function):
                 _ptr(bf), _ptr(a1), R, C1, dt_id, _stream())
         # ---- conv2 + max-pool ----
         W2 = weight_cache.get(w2, adt).reshape(C2, C1)
-        f = torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
-        fg = torch.empty(BG, C2, dtype=adt, device=dev)
-        arg1 = torch.empty(BG, C2, dtype=torch.uint8, device=dev)
-        _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(f), None,
-                _ptr(fg), _ptr(arg1), BG, K, C2, dt_id, _stream())
+        pool_fused = gemm.FUSE_POOL and K == 32 and gemm.supported(a1, W2)
+        if pool_fused:      # conv2 + bias + max-pool in one launch: f is written for conv3, (fg, arg1) come from the same tile
+            f, fg, arg1 = gemm.linear_pool(a1, W2, _c32(b2), bias_after_pool=False, want_rows=True)
+        else:
+            f = torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
+            fg = torch.empty(BG, C2, dtype=adt, device=dev)
+            arg1 = torch.empty(BG, C2, dtype=torch.uint8, device=dev)
+            _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(f), None,
+                    _ptr(fg), _ptr(arg1), BG, K, C2, dt_id, _stream())
         # ---- conv3 on [global | local] ----
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
         W3g, W3l = W3[:, :C2], W3[:, C2:]
@@ -134,12 +139,16 @@ class EmbedFn(torch.autograd.Function):
                 _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, 0.0, dt_id, _stream())
         # ---- conv4 + max-pool ----
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
-        z = a2 @ W4.t()
-        tok = torch.empty(BG, C4, dtype=adt, device=dev)
-        arg2 = torch.empty(BG, C4, dtype=torch.uint8, device=dev)
         b4f = _c32(b4)
-        _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
-                _ptr(b4f), _ptr(tok), _ptr(arg2), BG, K, C4, dt_id, _stream())
+        if gemm.FUSE_POOL and K == 32 and gemm.supported(a2, W4):
+            # conv4 + max-pool + bias: the (rows, 384) product never reaches HBM (the backward needs only arg2)
+            _, tok, arg2 = gemm.linear_pool(a2, W4, b4f, bias_after_pool=True, want_rows=False)
+        else:
+            z = a2 @ W4.t()
+            tok = torch.empty(BG, C4, dtype=adt, device=dev)
+            arg2 = torch.empty(BG, C4, dtype=torch.uint8, device=dev)
+            _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
+                    _ptr(b4f), _ptr(tok), _ptr(arg2), BG, K, C4, dt_id, _stream())
         if meta["grad"] and any(ctx.needs_input_grad):
             if not training:
                 raise NotImplementedError("EmbedFn backward is implemented for train-mode BatchNorm only")

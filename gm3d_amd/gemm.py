@@ -10,8 +10,11 @@ import torch
 from ._capi import lib
 from .ops import _launch, _ptr, _stream
 
-ENABLED = True
-FUSE_GELU = True      # fc1 + bias + GELU as one launch in the fused transformer stack
+import os
+
+ENABLED = os.environ.get("GM3D_OWN_GEMM", "1") == "1"
+FUSE_GELU = os.environ.get("GM3D_FUSE_GELU", "1") == "1"      # fc1 + bias + GELU as one launch in the fused transformer stack
+FUSE_POOL = os.environ.get("GM3D_FUSE_POOL", "1") == "1"      # mini-PointNet conv + max-pool as one launch
 
 
 def supported(x, w):
@@ -49,3 +52,16 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
 def prefer_own(M, N, K):
     """Shapes where the hand-written kernel beats the tuned hipBLASLt solution on MI355X (tools/gemm_kbench.py)."""
     return (N, K) == (384, 384) or ((N, K) == (1152, 384) and M <= 4096) or ((N, K) == (128, 256) and M >= 65536)
+
+
+def linear_pool(x, w, bias, bias_after_pool, want_rows):
+    """Conv1d(k=1) over (groups*32, K) rows + max over each group's 32 rows in the GEMM epilogue.
+    -> (rows (M,N) bf16 | None, pooled (M/32,N) bf16, argmax (M/32,N) uint8)."""
+    M, K = x.shape
+    N = w.shape[0]
+    rows = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_rows else None
+    pooled = torch.empty(M // 32, N, dtype=torch.bfloat16, device=x.device)
+    arg = torch.empty(M // 32, N, dtype=torch.uint8, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
+            _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), _stream())
+    return rows, pooled, arg

@@ -267,6 +267,13 @@ int gm3d_gemm_tn_bf16(const void *A, const void *W, const float *bias, void *C, 
  * Same operand rules and limits as gm3d_gemm_tn_bf16. */
 int gm3d_gemm_tn_bf16_gelu(const void *A, const void *W, const float *bias, void *F, void *G, int M, int N, int K, int lda,
                            int ldw, int ldf, int ldg, gm3d_stream_t stream);
+/* Conv1d(k=1) + max over the 32 points of each group in the GEMM epilogue (mini-PointNet, models_mae_learn_loss.py:891-897):
+ * rows are (group, point) with 32 points per group (M % 32 == 0).  P (M/32,N) bf16 = max_k, arg (M/32,N) u8 = its first argmax.
+ * bias_after_pool = 0: C (optional) = A.W^T + bias is written and pooled (conv2: the rows feed the next layer);
+ * bias_after_pool = 1: the product is pooled and the bias added to the maximum (conv4: C may be NULL -- the (M,N) product is
+ * never needed again, not even by the backward, which works from `arg`). */
+int gm3d_gemm_tn_bf16_pool(const void *A, const void *W, const float *bias, void *C, void *P, uint8_t *arg, int M, int N, int K,
+                           int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -61,3 +61,25 @@ def test_gemm_gelu_epilogue(M, with_f):
         assert torch.equal(two, gg)
     gref = torch.nn.functional.gelu(fref.bfloat16().float() + b)
     assert float((gg.float() - gref).abs().max()) <= 2.0 ** -6 * float(gref.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("groups,K,N,after,rows", [(8192, 128, 256, False, True), (8192, 512, 384, True, False), (37, 128, 256, False, True),
+                                                   (5, 512, 384, True, False)])
+def test_gemm_pool_epilogue(groups, K, N, after, rows):
+    """conv + max over the 32 rows of each group in the GEMM epilogue == the same GEMM followed by gm3d_group_max_fwd."""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    M = groups * 32
+    g = torch.Generator(device="cuda").manual_seed(groups + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) * 0.2
+    full, pooled, arg = gemm.linear_pool(x, w, b, bias_after_pool=after, want_rows=rows)
+    z = gemm.linear_tn(x, w, None if after else b)             # same kernel, same accumulation order: bit-identical rows
+    if rows:
+        assert torch.equal(full, z)
+    want = torch.empty(groups, N, device="cuda", dtype=torch.bfloat16)
+    warg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
+    check(lib.gm3d_group_max_fwd(_ptr(z), _ptr(b) if after else None, _ptr(want), _ptr(warg), groups, 32, N, 1, _stream()), "gmax")
+    assert torch.equal(pooled, want) and torch.equal(arg, warg)
