@@ -51,6 +51,8 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tile_rows": [_i],
     "gm3d_mask_select": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gm3d_bn_finalize": [_vp, ctypes.c_double, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "gm3d_pn1_finalize": [_vp, ctypes.c_double, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],

@@ -29,7 +29,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
                                                               int N, int K, int lda, int ldw, int ldc, int tiles_n,
                                                               int total_tiles, bf16_t* __restrict__ G, int ldg,
                                                               bf16_t* __restrict__ P, uint8_t* __restrict__ ARG, int ldp,
-                                                              int bias_after_pool) {
+                                                              int bias_after_pool, const bf16_t* __restrict__ Fpre, int ldfp,
+                                                              float* __restrict__ colpart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(gsm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
         }
         if (!C) return;
     }
+    float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int c = tid + 256 * i;                 // 128 rows x 16 chunks of 8 columns
@@ -175,7 +177,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
                 const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + nc), b1 = *reinterpret_cast<const float4*>(bias + n0 + nc + 4);
                 bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
             }
-            if (G) {
+            if (Fpre) {
+                // fc2 input-gradient epilogue: C = bf16(dg) * GELU'(f + bias) (dg rounded to bf16 first, like a stored GEMM
+                // result); per-tile column sums of the fp32 products -> colpart (the fc1 bias gradient, finished later)
+                float fv[8];
+                V8<bf16_t>::load(Fpre + (size_t)(m0 + row) * ldfp + n0 + nc, fv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] = (float)(bf16_t)v[e] * gelu_grad_f<bf16_t>(fv[e] + bv[e]);
+                    csum[e] += v[e];
+                }
+                V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+            } else if (G) {
                 // fc1 epilogue: C (optional) = the pre-activation WITHOUT bias, rounded to bf16 -- what the GELU backward
                 // re-reads; G = GELU(bf16(f) + bias), from the rounded value so forward and backward see the same f
                 if (C) V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
@@ -189,13 +202,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
             }
         }
     }
+    if (Fpre) {      // the 16 threads that share a column chunk meet in LDS (the fp32 tile is no longer needed)
+        __syncthreads();
+        const int nc = (tid & 15) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[(tid >> 4) * GBN + nc + e] = csum[e];
+        __syncthreads();
+        if (tid < GBN) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += cs[k * GBN + tid];
+            colpart[(size_t)tile_m * N + n0 + tid] = t;
+        }
+    }
 }
 
 }  // namespace gm3d
 
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                        void* G, int ldg, gm3d_stream_t stream, void* P = nullptr, uint8_t* ARG = nullptr, int ldp = 0,
-                       int bias_after_pool = 0) {
+                       int bias_after_pool = 0, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr) {
     using namespace gm3d;
     if (!A || !W || (!C && !G && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp < N)) return GM3D_EINVAL;
@@ -218,7 +244,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
         }                                                                                                                     \
         hipLaunchKernelGGL(gemm_tn_bf16_kernel<KTT>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,       \
                            (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,      \
-                           (bf16_t*)P, ARG, ldp, bias_after_pool);                                                           \
+                           (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart);                        \
         break;                                                                                                                \
     }
     switch (K / GBK) {
@@ -233,7 +259,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
             }
             hipLaunchKernelGGL(gemm_tn_bf16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,
                                (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,
-                               (bf16_t*)P, ARG, ldp, bias_after_pool);
+                               (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart);
         }
     }
 #undef GM3D_GEMM_CASE
@@ -258,3 +284,11 @@ extern "C" int gm3d_gemm_tn_bf16_pool(const void* A, const void* W, const float*
     if (!P || !arg) return GM3D_EINVAL;
     return gemm_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, nullptr, 0, stream, P, arg, ldp, bias_after_pool);
 }
+
+extern "C" int gm3d_gemm_tn_bf16_gelu_bwd(const void* dO, const void* Wt, const void* F, const float* bias, void* dF, float* colpart,
+                                          int M, int N, int K, int lda, int ldw, int ldf, int lddf, gm3d_stream_t stream) {
+    if (!F || !bias || !dF || !colpart || ldf % 8 || ldf < N) return GM3D_EINVAL;
+    return gemm_launch(dO, Wt, bias, dF, M, N, K, lda, ldw, lddf, nullptr, 0, stream, nullptr, nullptr, 0, 0, F, ldf, colpart);
+}
+
+extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gm3d::GBM - 1) / gm3d::GBM; }

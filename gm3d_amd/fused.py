@@ -293,7 +293,16 @@ class TransformerStackFn(torch.autograd.Function):
         # GELU site, finished by ONE launch each after the loop
         PLN = torch.empty(2 * nblk + 1, lib.gm3d_ln_partial_rows(R), 3 * C, dtype=torch.float32, device=dev)
         SLN = torch.empty(2 * nblk + 1, 3, C, dtype=torch.float32, device=dev)
-        PGL = torch.empty(nblk, lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32, device=dev)
+        # fc2 input gradient + GELU backward + fc1 bias-gradient partials as ONE launch of the hand-written GEMM (bf16 path):
+        # it wants fc2.weight^T (and proj.weight^T for the attention branch), produced for the whole stack by one strided
+        # transposing copy each from the optimizer's flat bf16 shadow
+        w2s = [weight_cache.get(params[i * PER_BLOCK + 9], adt) for i in range(nblk)]
+        fuse_mlp_bwd = gemm.ENABLED and gemm.FUSE_GELU_BWD and adt == torch.bfloat16 and dh.is_cuda
+        if fuse_mlp_bwd:
+            W2T = gemm.stacked_transpose(w2s)                                                                   # (nblk, C, 4C)^T -> (nblk, 4C, C)
+            WPT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 3], adt) for i in range(nblk)])  # (nblk, C, C)
+        PGL = torch.empty(nblk, gemm.tile_rows(R) if fuse_mlp_bwd else lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32,
+                          device=dev)
         SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
         dp2_last = meta["dp"][nblk - 1][1]
         G, d_o, _ = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1],
@@ -308,15 +317,18 @@ class TransformerStackFn(torch.autograd.Function):
             gi = grads[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             # mlp branch: x2 = x1 + dp2 * (g @ W2^T + b2)
             gi[10] = db2
-            dg = d_o @ weight_cache.get(w2, adt)
-            df, _ = bias_gelu_bwd(dg, f, b1, adt, df=DF[i], partial=PGL[i])
+            if fuse_mlp_bwd:
+                df = gemm.linear_gelu_bwd(d_o, W2T[i], f, b1, DF[i], PGL[i])
+            else:
+                dg = d_o @ weight_cache.get(w2, adt)
+                df, _ = bias_gelu_bwd(dg, f, b1, adt, df=DF[i], partial=PGL[i])
             gi[8] = SGL[i]
             dh2 = df @ weight_cache.get(w1, adt)
             dx1, d_p, _ = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R, dy=DP[i],
                                           partial=PLN[2 * i + 1])
             gi[5], gi[6], gi[4] = SLN[2 * i + 1, 0], SLN[2 * i + 1, 1], SLN[2 * i + 1, 2]
             # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
-            da = d_p @ weight_cache.get(wproj, adt)
+            da = gemm.linear_tn(d_p, WPT[i]) if fuse_mlp_bwd else d_p @ weight_cache.get(wproj, adt)
             dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
             dh1 = dqkv @ weight_cache.get(wqkv, adt)
             G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,

@@ -15,6 +15,7 @@ import os
 ENABLED = os.environ.get("GM3D_OWN_GEMM", "1") == "1"
 FUSE_GELU = os.environ.get("GM3D_FUSE_GELU", "1") == "1"      # fc1 + bias + GELU as one launch in the fused transformer stack
 FUSE_POOL = os.environ.get("GM3D_FUSE_POOL", "1") == "1"      # mini-PointNet conv + max-pool as one launch
+FUSE_GELU_BWD = os.environ.get("GM3D_FUSE_GELU_BWD", "1") == "1"   # fc2 input gradient + GELU backward + fc1 bias-gradient partials
 
 
 def supported(x, w):
@@ -65,3 +66,33 @@ def linear_pool(x, w, bias, bias_after_pool, want_rows):
     _launch("gm3d_gemm_tn_bf16_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
             _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), _stream())
     return rows, pooled, arg
+
+
+def tile_rows(M):
+    return lib.gm3d_gemm_tile_rows(int(M))
+
+
+def linear_gelu_bwd(d_o, w2t, f, bias, df, colpart):
+    """df = (d_o @ w2t^T) * GELU'(f + bias); w2t (hidden, C) = fc2.weight^T in bf16; colpart (tile_rows(M), hidden) f32."""
+    M, K = d_o.shape
+    N = w2t.shape[0]
+    _launch("gm3d_gemm_tn_bf16_gelu_bwd", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_gelu_bwd, _ptr(d_o), _ptr(w2t), _ptr(f),
+            _ptr(bias), _ptr(df), _ptr(colpart), M, N, K, d_o.stride(0), w2t.stride(0), f.stride(0), df.stride(0), _stream())
+    return df
+
+
+def stacked_transpose(ws):
+    """[w_0 .. w_{n-1}] (each (N,K) bf16) -> (n, K, N) contiguous = the transposes, in ONE copy launch when the tensors sit at a
+    constant stride in one buffer (the flat optimizer's bf16 shadow), two otherwise."""
+    w0 = ws[0]
+    n = len(ws)
+    if n > 1:
+        step = ws[1].data_ptr() - w0.data_ptr()
+        regular = step > 0 and step % w0.element_size() == 0 and all(
+            w.shape == w0.shape and w.is_contiguous() and w.untyped_storage().data_ptr() == w0.untyped_storage().data_ptr()
+            and w.data_ptr() - w0.data_ptr() == i * step for i, w in enumerate(ws))
+        if regular:
+            N, K = w0.shape
+            v = torch.as_strided(w0, (n, N, K), (step // w0.element_size(), K, 1))
+            return v.transpose(1, 2).contiguous()
+    return torch.stack(list(ws)).transpose(1, 2).contiguous()

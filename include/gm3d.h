@@ -274,6 +274,13 @@ int gm3d_gemm_tn_bf16_gelu(const void *A, const void *W, const float *bias, void
  * never needed again, not even by the backward, which works from `arg`). */
 int gm3d_gemm_tn_bf16_pool(const void *A, const void *W, const float *bias, void *C, void *P, uint8_t *arg, int M, int N, int K,
                            int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
+/* fc2 input gradient + GELU backward in the GEMM epilogue (timm Mlp backward): dF (M,N) bf16 = (dO (M,K) . Wt (N,K)^T) *
+ * GELU'(F + bias) with Wt the TRANSPOSED fc2 weight (N = hidden, K = model width), F the bf16 pre-activation saved by
+ * gm3d_gemm_tn_bf16_gelu; colpart (gm3d_gemm_tile_rows(M), N) f32 receives per-row-tile column sums of dF (the fc1 bias
+ * gradient after gm3d_colsum_finish). */
+int gm3d_gemm_tn_bf16_gelu_bwd(const void *dO, const void *Wt, const void *F, const float *bias, void *dF, float *colpart, int M,
+                               int N, int K, int lda, int ldw, int ldf, int lddf, gm3d_stream_t stream);
+int gm3d_gemm_tile_rows(int M);
 
 #ifdef __cplusplus
 }

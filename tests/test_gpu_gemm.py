@@ -83,3 +83,38 @@ def test_gemm_pool_epilogue(groups, K, N, after, rows):
     warg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
     check(lib.gm3d_group_max_fwd(_ptr(z), _ptr(b) if after else None, _ptr(want), _ptr(warg), groups, 32, N, 1, _stream()), "gmax")
     assert torch.equal(pooled, want) and torch.equal(arg, warg)
+
+
+@pytest.mark.parametrize("M", [8192, 3200, 200])
+def test_gemm_gelu_bwd_epilogue(M):
+    """fc2 input gradient + GELU backward + bias-gradient partials in one launch == own GEMM then gm3d_bias_gelu_bwd."""
+    from gm3d_amd import gemm, fused
+    C, Hd = 384, 1536
+    g = torch.Generator(device="cuda").manual_seed(M + 1)
+    d_o = torch.randn(M, C, device="cuda", generator=g).bfloat16()
+    w2 = (torch.randn(C, Hd, device="cuda", generator=g) / Hd ** 0.5).bfloat16()          # fc2.weight (out=C, in=Hd)
+    f = torch.randn(M, Hd, device="cuda", generator=g).bfloat16()
+    b1 = torch.randn(Hd, device="cuda", generator=g) * 0.3
+    w2t = gemm.stacked_transpose([w2])[0]
+    assert w2t.shape == (Hd, C) and torch.equal(w2t, w2.t())
+    df = torch.empty(M, Hd, device="cuda", dtype=torch.bfloat16)
+    part = torch.empty(gemm.tile_rows(M), Hd, device="cuda")
+    gemm.linear_gelu_bwd(d_o, w2t, f, b1, df, part)
+    dg = gemm.linear_tn(d_o, w2t)                                   # same kernel: identical accumulation
+    want, db = fused.bias_gelu_bwd(dg, f, b1, torch.bfloat16)
+    assert torch.equal(df, want)
+    got_db = part.sum(0)
+    assert float((got_db - db).abs().max()) <= 1e-4 * float(db.abs().max()) + 1e-4
+    ref = (d_o.float() @ w2.float())
+    assert float((dg.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
+def test_stacked_transpose_strided_view():
+    from gm3d_amd import gemm
+    flat = torch.randn(5 * 1000 + 7, device="cuda").bfloat16()
+    ws = [flat[7 + i * 1000: 7 + i * 1000 + 24 * 16].view(24, 16) for i in range(5)]      # constant stride in one buffer
+    out = gemm.stacked_transpose(ws)
+    assert out.shape == (5, 16, 24) and all(torch.equal(out[i], ws[i].t()) for i in range(5))
+    loose = [torch.randn(24, 16, device="cuda").bfloat16() for _ in range(3)]
+    out = gemm.stacked_transpose(loose)
+    assert all(torch.equal(out[i], loose[i].t()) for i in range(3))
