@@ -1,10 +1,6 @@
-"""bf16 GEMM of the block / mini-PointNet shapes on the hand-written MFMA kernel (csrc/gemm.hip): y = x @ w^T (+ bias).
-
-Status (round 1, tools/gemm_kbench.py on MI355X): correct (tests/test_gpu_gemm.py) but NOT yet faster than the tuned hipBLASLt
-solutions the step uses -- 0.43x..1.10x across the step's 18 shapes (340-520 TFLOP/s on the large ones vs 430-700): the
-128x128 tile with a 2-deep register-prefetch pipeline is bound by global-load latency (64 KB in flight per CU).  It is therefore
-not wired into the model; the next step is a 256x128 tile with a 3-4 deep direct-to-LDS pipeline, then the bias/GELU/residual
-epilogues that are the real reason to own this kernel."""
+"""bf16 GEMM of the block / mini-PointNet shapes on the hand-written MFMA kernel (csrc/gemm.hip): y = x @ w^T (+ bias), and
+its fused-epilogue forms (fc1+GELU, fc2-dgrad+GELU', conv+max-pool).  DESIGN.md 3b' has the design and the measurements;
+`prefer_own` lists the plain shapes where the kernel beats the tuned hipBLASLt solution (tools/gemm_kbench.py)."""
 import torch
 
 from ._capi import lib
