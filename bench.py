@@ -47,6 +47,8 @@ def algorithmic(name, meta):
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
     if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
+    if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMM (+ epilogues): 2*M*N*K flop
+        return "mfma", 2.0 * meta["M"] * meta["N"] * meta["K"], "FLOP"
     sz = 2 if "bfloat16" in str(meta.get("dtype", "")) else 4
     if name == "gm3d_residual_ln_fwd":   # res in/out fp32, y + add in, h out
         return "hbm", meta["R"] * 384 * (8 + 3 * sz), "B"
@@ -73,16 +75,26 @@ def algorithmic(name, meta):
     return None
 
 
-def pmc_traffic(kernel, dtype):
+def _gemm_grid(meta):
+    tiles = -(-meta["M"] // 128) * (meta["N"] // 128)
+    return (tiles + 7) // 8 * 8 * 256
+
+
+def pmc_traffic(kernel, dtype, metas=()):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_g_pmc_fetch_write_per_launch.json), corrected as
+    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_h_pmc_fetch_write_per_launch.json), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: counters are in KB, and FETCH_SIZE reports half of a coalesced stream.
     Launch-weighted mean over the kernel's shapes in the step.  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_g_pmc_fetch_write_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_fetch_write_per_launch.json")
     if not os.path.exists(path):
         return None
-    tag = kernel.replace("gm3d_", "gm3d::") + "_kernel"
-    rows = [r for r in json.load(open(path)) if r["kernel"].startswith(tag) and (dtype in r["kernel"] or "<" not in r["kernel"])]
+    if kernel.startswith("gm3d_gemm_tn_bf16"):
+        # the four GEMM entry points share one kernel: pick the PMC rows by launch grid (= the timed launches' tile counts)
+        grids = {_gemm_grid(m) for m in metas}
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_bf16_kernel") and r["grid_threads"] in grids]
+    else:
+        tag = kernel.replace("gm3d_", "gm3d::") + "_kernel"
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith(tag) and (dtype in r["kernel"] or "<" not in r["kernel"])]
     n = sum(r["launches"] for r in rows)
     if not n:
         return None
@@ -295,7 +307,7 @@ def main():
                                    "random-init weights" % (args.batch, args.epoch),
                        "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
-                         "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype),
+                         "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype, [m for _, m in tsum["per_launch"]]),
                          "avg_launch_us": raw_avg_ms * 1e3, "empty_bracket_us": overhead_ms * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
             "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if use_dist else "")) if use_graph
