@@ -23,7 +23,8 @@ def dev(t):
 
 
 @pytest.mark.parametrize("family", list(clouds.FAMILIES))
-@pytest.mark.parametrize("N,G", [(1024, 64), (100, 17), (2048, 128), (300, 300)])
+@pytest.mark.parametrize("N,G", [(1024, 64), (100, 17), (2048, 128), (300, 300), (8192, 1200), (4096, 512), (5000, 100), (2048, 512),
+                                 (12000, 64)])
 def test_fps_index_exact(gops, oracle_ops, family, N, G):
     x = clouds.FAMILIES[family](3, N, seed=11)
     ref = oracle_ops.furthest_point_sample(x, G)
