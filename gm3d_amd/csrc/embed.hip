@@ -606,7 +606,8 @@ __global__ void pn1_bwd_finalize_kernel(const double* __restrict__ q, const doub
 // P/:298-299,649-650), written through ballot + popcount prefix positions.
 __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict__ loss_pred, const float* __restrict__ noise,
                                                          int L, int len_keep, int len_loss, float* __restrict__ mask,
-                                                         long long* __restrict__ vis_ids, long long* __restrict__ mask_ids) {
+                                                         long long* __restrict__ vis_ids, long long* __restrict__ mask_ids,
+                                                         int vis_pitch, int mask_pitch) {
     const int b = blockIdx.x, l = threadIdx.x;
     const bool in = l < L;
     const float lp = in ? loss_pred[(size_t)b * L + l] : 0.f;
@@ -627,8 +628,59 @@ __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict
     const unsigned long long below = l == 0 ? 0ull : (~0ull >> (64 - l));
     if (in) {
         mask[(size_t)b * L + l] = keep ? 0.f : 1.f;
-        if (keep) vis_ids[(size_t)b * len_keep + __popcll(kb & below)] = l;
-        else mask_ids[(size_t)b * (L - len_keep) + __popcll(mb & below)] = l;
+        if (keep) vis_ids[(size_t)b * vis_pitch + __popcll(kb & below)] = l;
+        else mask_ids[(size_t)b * mask_pitch + __popcll(mb & below)] = l;
+    }
+}
+
+// ------------------------------------------------------------------ token / positional-embedding assembly around the mask
+// order (B,L) = [visible ids ascending | masked ids ascending] (a permutation of 0..L-1 per sample, gm3d_mask_select).
+// Forward: x_vis[b,j] = tokens[b,order[b,j]] and pos_vis[b,j] = pos[b,order[b,j]] for j < V; pos_full[b,j] = pos[b,order[b,j]]
+// for all j -- the boolean-mask gathers and the concat of P/models_mae_learn_loss.py:298-300,649-658 in one pass.
+// Backward: because `order` is a permutation every source row is written exactly once (no atomics, no zero fill):
+// dtokens[b,order[b,j]] = j < V ? dx_vis[b,j] : 0 ; dpos[b,order[b,j]] = dpos_full[b,j] + (j < V ? dpos_vis[b,j] : 0).
+template <class T>
+__global__ __launch_bounds__(64) void token_assemble_fwd_kernel(const T* __restrict__ tokens, const T* __restrict__ pos,
+                                                                const long long* __restrict__ order, int L, int V, int C,
+                                                                T* __restrict__ x_vis, T* __restrict__ pos_vis,
+                                                                T* __restrict__ pos_full) {
+    const int b = blockIdx.x / L, j = blockIdx.x - b * L;
+    const int i = (int)order[(size_t)b * L + j];
+    const size_t src = ((size_t)b * L + i) * C, dfull = ((size_t)b * L + j) * C, dvis = ((size_t)b * V + j) * C;
+    for (int c = threadIdx.x * 8; c < C; c += 64 * 8) {
+        float p[8];
+        V8<T>::load(pos + src + c, p);
+        V8<T>::store(pos_full + dfull + c, p);
+        if (j < V) {
+            V8<T>::store(pos_vis + dvis + c, p);
+            float t[8];
+            V8<T>::load(tokens + src + c, t);
+            V8<T>::store(x_vis + dvis + c, t);
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void token_assemble_bwd_kernel(const T* __restrict__ dx_vis, const T* __restrict__ dpos_vis,
+                                                                const T* __restrict__ dpos_full, const long long* __restrict__ order,
+                                                                int L, int V, int C, T* __restrict__ dtokens, T* __restrict__ dpos) {
+    const int b = blockIdx.x / L, j = blockIdx.x - b * L;
+    const int i = (int)order[(size_t)b * L + j];
+    const size_t dst = ((size_t)b * L + i) * C, sfull = ((size_t)b * L + j) * C, svis = ((size_t)b * V + j) * C;
+    for (int c = threadIdx.x * 8; c < C; c += 64 * 8) {
+        float g[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (dpos_full) V8<T>::load(dpos_full + sfull + c, g);
+        if (j < V) {
+            if (dpos_vis) {
+                float v[8];
+                V8<T>::load(dpos_vis + svis + c, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] += v[e];
+            }
+            if (dx_vis) V8<T>::load(dx_vis + svis + c, t);
+        }
+        V8<T>::store(dpos + dst + c, g);
+        V8<T>::store(dtokens + dst + c, t);
     }
 }
 
@@ -933,14 +985,49 @@ extern "C" int gm3d_pn1_bwd_finalize(const double* q, const double* mcov, const 
 }
 
 extern "C" int gm3d_mask_select(const float* loss_pred, const float* noise, int B, int L, int len_keep, int len_loss,
-                                float* mask, long long* vis_ids, long long* mask_ids, gm3d_stream_t stream) {
+                                float* mask, long long* vis_ids, long long* mask_ids, int id_pitch, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!loss_pred || !noise || !mask || !vis_ids || !mask_ids || B < 0 || L < 1) return GM3D_EINVAL;
     if (len_keep < 0 || len_loss < 0 || len_keep + len_loss > L) return GM3D_EINVAL;
     if (L > 64) return GM3D_EUNSUPPORTED;
     if (B == 0) return GM3D_OK;
+    if (id_pitch != 0 && id_pitch < L) return GM3D_EINVAL;
     hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, loss_pred, noise, L, len_keep, len_loss,
-                       mask, vis_ids, mask_ids);
+                       mask, vis_ids, mask_ids, id_pitch ? id_pitch : len_keep, id_pitch ? id_pitch : L - len_keep);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_token_assemble_fwd(const void* tokens, const void* pos, const long long* order, int B, int L, int V, int C,
+                                       void* x_vis, void* pos_vis, void* pos_full, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!tokens || !pos || !order || !x_vis || !pos_vis || !pos_full || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;
+    if (C % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(token_assemble_fwd_kernel<bf16_t>, dim3(B * L), dim3(64), 0, st, (const bf16_t*)tokens,
+                                     (const bf16_t*)pos, order, L, V, C, (bf16_t*)x_vis, (bf16_t*)pos_vis, (bf16_t*)pos_full),
+                  hipLaunchKernelGGL(token_assemble_fwd_kernel<float>, dim3(B * L), dim3(64), 0, st, (const float*)tokens,
+                                     (const float*)pos, order, L, V, C, (float*)x_vis, (float*)pos_vis, (float*)pos_full));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_token_assemble_bwd(const void* dx_vis, const void* dpos_vis, const void* dpos_full, const long long* order, int B,
+                                       int L, int V, int C, void* dtokens, void* dpos, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!order || !dtokens || !dpos || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;
+    if (C % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(token_assemble_bwd_kernel<bf16_t>, dim3(B * L), dim3(64), 0, st, (const bf16_t*)dx_vis,
+                                     (const bf16_t*)dpos_vis, (const bf16_t*)dpos_full, order, L, V, C, (bf16_t*)dtokens, (bf16_t*)dpos),
+                  hipLaunchKernelGGL(token_assemble_bwd_kernel<float>, dim3(B * L), dim3(64), 0, st, (const float*)dx_vis,
+                                     (const float*)dpos_vis, (const float*)dpos_full, order, L, V, C, (float*)dtokens, (float*)dpos));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -217,6 +217,35 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     }
 }
 
+// Batched bf16 transpose dst[b][c][r] = src[b][r][c] (64x64 LDS tiles, 16-byte global accesses on both sides): the per-step
+// transposed weight shadows of the input-gradient GEMMs (20 blocks x (fc2 + proj) per step; the generic strided-copy kernel
+// runs this at ~1 TB/s).
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst, int rows,
+                                                             int cols, size_t src_bstride) {
+    __shared__ bf16_t tile[64][66];
+    const bf16_t* s = src + (size_t)blockIdx.z * src_bstride;
+    bf16_t* d = dst + (size_t)blockIdx.z * rows * cols;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;       // 32 rows x 8 chunks per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int rr = tr + 32 * p;
+        float v[8];
+        V8<bf16_t>::load(s + (size_t)(r0 + rr) * cols + c0 + tc, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[rr][tc + e] = (bf16_t)v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int cc = tr + 32 * p;                                     // output row = source column
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)tile[tc + e][cc];
+        V8<bf16_t>::store(d + (size_t)(c0 + cc) * rows + r0 + tc, v);
+    }
+}
+
 }  // namespace gm3d
 
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
@@ -292,3 +321,15 @@ extern "C" int gm3d_gemm_tn_bf16_gelu_bwd(const void* dO, const void* Wt, const 
 }
 
 extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gm3d::GBM - 1) / gm3d::GBM; }
+
+extern "C" int gm3d_transpose_bf16_batched(const void* src, void* dst, int batch, int rows, int cols, long long src_batch_stride,
+                                           gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!src || !dst || batch < 0 || rows < 1 || cols < 1 || src_batch_stride < (long long)rows * cols) return GM3D_EINVAL;
+    if (rows % 64 || cols % 64 || batch > 65535) return GM3D_EUNSUPPORTED;
+    if (batch == 0) return GM3D_OK;
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cols / 64, rows / 64, batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       (bf16_t*)dst, rows, cols, (size_t)src_batch_stride);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

@@ -87,6 +87,12 @@ def stacked_transpose(ws):
         regular = step > 0 and step % w0.element_size() == 0 and all(
             w.shape == w0.shape and w.is_contiguous() and w.untyped_storage().data_ptr() == w0.untyped_storage().data_ptr()
             and w.data_ptr() - w0.data_ptr() == i * step for i, w in enumerate(ws))
+        if regular and w0.shape[0] % 64 == 0 and w0.shape[1] % 64 == 0 and w0.dtype == torch.bfloat16:
+            N, K = w0.shape
+            out = torch.empty(n, K, N, dtype=w0.dtype, device=w0.device)
+            _launch("gm3d_transpose_bf16_batched", {"batch": n, "rows": N, "cols": K}, lib.gm3d_transpose_bf16_batched, _ptr(w0),
+                    _ptr(out), n, N, K, step // w0.element_size(), _stream())
+            return out
         if regular:
             N, K = w0.shape
             v = torch.as_strided(w0, (n, N, K), (step // w0.element_size(), K, 1))

@@ -211,3 +211,50 @@ class _RankLoss(torch.autograd.Function):
 
 def rank_loss(pred, target):
     return _RankLoss.apply(pred, target)
+
+
+class TokenAssembleFn(torch.autograd.Function):
+    """tokens, pos (B,L,C), order (B,L) int64 = [visible ids | masked ids], V -> x_vis, pos_vis (B,V,C), pos_full (B,L,C):
+    the boolean-mask gathers + concat of P/models_mae_learn_loss.py:298-300,649-658 as one launch; backward one launch, exact
+    (order is a permutation: no atomics)."""
+
+    @staticmethod
+    def forward(ctx, tokens, pos, order, V):
+        B, L, C = tokens.shape
+        dt = tokens.dtype
+        tokens = tokens.contiguous()
+        pos = pos.to(dt).contiguous()
+        order = order.contiguous()
+        x_vis = torch.empty(B, V, C, dtype=dt, device=tokens.device)
+        pos_vis = torch.empty(B, V, C, dtype=dt, device=tokens.device)
+        pos_full = torch.empty(B, L, C, dtype=dt, device=tokens.device)
+        _launch("gm3d_token_assemble_fwd", {"B": B, "L": L, "C": C}, lib.gm3d_token_assemble_fwd, _ptr(tokens), _ptr(pos), _ptr(order),
+                B, L, V, C, _ptr(x_vis), _ptr(pos_vis), _ptr(pos_full), _DT[dt], _stream())
+        ctx.save_for_backward(order)
+        ctx.dims, ctx.dt, ctx.pdt = (B, L, V, C), dt, pos.dtype
+        return x_vis, pos_vis, pos_full
+
+    @staticmethod
+    def backward(ctx, dx_vis, dpos_vis, dpos_full):
+        (order,) = ctx.saved_tensors
+        B, L, V, C = ctx.dims
+        dt = ctx.dt
+        g = [None if t is None else t.to(dt).contiguous() for t in (dx_vis, dpos_vis, dpos_full)]
+        dtokens = torch.empty(B, L, C, dtype=dt, device=order.device)
+        dpos = torch.empty(B, L, C, dtype=dt, device=order.device)
+        _launch("gm3d_token_assemble_bwd", {"B": B, "L": L, "C": C}, lib.gm3d_token_assemble_bwd, _ptr(g[0]), _ptr(g[1]), _ptr(g[2]),
+                _ptr(order), B, L, V, C, _ptr(dtokens), _ptr(dpos), _DT[dt], _stream())
+        return dtokens, dpos, None, None
+
+
+def token_assemble(tokens, pos, vis_ids, mask_ids, order=None):
+    if order is None:
+        L = vis_ids.shape[1] + mask_ids.shape[1]
+        if (vis_ids.stride(0) == L and vis_ids.stride(1) == 1 and mask_ids.shape[1] and mask_ids.stride(0) == L and
+                mask_ids.data_ptr() == vis_ids.data_ptr() + vis_ids.shape[1] * vis_ids.element_size()):
+            order = torch.as_strided(vis_ids, (vis_ids.shape[0], L), (L, 1))      # the two halves of one (B,L) buffer
+        elif mask_ids.shape[1] == 0:
+            order = vis_ids
+        else:
+            order = torch.cat([vis_ids, mask_ids], dim=1)
+    return TokenAssembleFn.apply(tokens, pos, order, vis_ids.shape[1])

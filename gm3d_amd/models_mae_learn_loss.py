@@ -359,7 +359,16 @@ class MaskedAutoencoderViT(nn.Module):
         vis_ids, mask_ids = ids if ids is not None else split_ids(mask, num_visible)   # ids: precomputed (generate_mask_ids)
         if pos_all is None:
             pos_all = self.embed_pos(center)
-        x_vis = self._encode_visible(neighborhood, vis_ids, pos_all, tokens)
+        pos_full = None
+        if FUSED_HEADS and pos_all.is_cuda:
+            # visible-token gather, its positional gather and the [visible | masked] positional concat in one launch
+            from . import heads
+            if tokens is None:
+                tokens = self.encoder(neighborhood)
+            tok_vis, pos_vis, pos_full = heads.token_assemble(tokens, pos_all, vis_ids, mask_ids)
+            x_vis = self.blocks(tok_vis, pos_vis, norm=self.norm_p)
+        else:
+            x_vis = self._encode_visible(neighborhood, vis_ids, pos_all, tokens)
         B, _, C = x_vis.shape
         if noaug:
             return x_vis
@@ -370,7 +379,8 @@ class MaskedAutoencoderViT(nn.Module):
         else:
             mask_tokens = self.mask_token.expand(B, N, -1).to(x_vis.dtype)
         x_full = torch.cat([x_vis, mask_tokens], dim=1)
-        pos_full = torch.cat([take(pos_all, vis_ids), take(pos_all, mask_ids)], dim=1)
+        if pos_full is None:
+            pos_full = torch.cat([take(pos_all, vis_ids), take(pos_all, mask_ids)], dim=1)
 
         # The two decoders are independent given x_full: each of their GEMMs (8192 rows) is at most one wave of tiles on
         # 256 CUs, so the loss-prediction decoder runs on a second HIP stream beside the reconstruction decoder (forward
@@ -463,10 +473,10 @@ class MaskedAutoencoderViT(nn.Module):
         noise = noise.to(dev, torch.float32).contiguous()
         lp = loss_pred.detach().float().contiguous()
         mask = torch.empty(N, L, dtype=torch.float32, device=dev)
-        vis_ids = torch.empty(N, len_keep, dtype=torch.int64, device=dev)
-        mask_ids = torch.empty(N, L - len_keep, dtype=torch.int64, device=dev)
+        order = torch.empty(N, L, dtype=torch.int64, device=dev)        # [visible ids | masked ids] per sample
+        vis_ids, mask_ids = order[:, :len_keep], order[:, len_keep:]
         ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
-                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), ops._stream())
+                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
         return mask, vis_ids, mask_ids
 
     def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False):

@@ -162,10 +162,10 @@ class MaskedAutoencoderViT(nn.Module):
         noise = torch.rand(N, L, device=dev) if noise is None else noise.to(dev, torch.float32).contiguous()
         lp = loss_pred.detach().float().contiguous()
         mask = torch.empty(N, L, dtype=torch.float32, device=dev)
-        vis_ids = torch.empty(N, len_keep, dtype=torch.int64, device=dev)
-        mask_ids = torch.empty(N, L - len_keep, dtype=torch.int64, device=dev)
+        order = torch.empty(N, L, dtype=torch.int64, device=dev)        # [visible ids | masked ids] per sample
+        vis_ids, mask_ids = order[:, :len_keep], order[:, len_keep:]
         ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
-                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), ops._stream())
+                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
         return mask, vis_ids, mask_ids
 
     @torch.no_grad()

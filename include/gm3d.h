@@ -254,9 +254,11 @@ int gm3d_pn1_bwd_finalize(const double *q, const double *mcov, const float *w, c
 /* Teacher-guided mask (models_mae_learn_loss.py:744-784 generate_mask) and the visible / masked token id lists the
  * boolean-mask indexing of :298-299,649-650 produces, in one launch.  loss_pred, noise (B,L) f32; the len_loss tokens of
  * highest loss_pred are always masked, the others are ranked by noise ((value, index) order) and the first len_keep stay
- * visible.  mask (B,L) f32: 0 keep / 1 remove; vis_ids (B,len_keep), mask_ids (B,L-len_keep) int64 ascending.  L <= 64. */
+ * visible.  mask (B,L) f32: 0 keep / 1 remove; vis_ids (B,len_keep), mask_ids (B,L-len_keep) int64 ascending.  L <= 64.
+ * id_pitch = 0: the two id arrays are dense; id_pitch >= L: their row pitch in elements (vis_ids = order, mask_ids = order + len_keep
+ * of one (B,id_pitch) buffer gives the [visible | masked] permutation gm3d_token_assemble_* consume). */
 int gm3d_mask_select(const float *loss_pred, const float *noise, int B, int L, int len_keep, int len_loss, float *mask,
-                     long long *vis_ids, long long *mask_ids, gm3d_stream_t stream);
+                     long long *vis_ids, long long *mask_ids, int id_pitch, gm3d_stream_t stream);
 /* C (M,N) bf16 = A (M,K) bf16 . W (N,K)^T bf16 (+ bias (N) f32), fp32 accumulation: nn.Linear / Conv1d(k=1) forward with W the
  * weight as stored, input gradient with W the transposed weight.  Row pitches lda / ldw / ldc in elements (multiples of 8).
  * Limits: N % 128 == 0, K % 64 == 0. */
@@ -281,6 +283,18 @@ int gm3d_gemm_tn_bf16_pool(const void *A, const void *W, const float *bias, void
 int gm3d_gemm_tn_bf16_gelu_bwd(const void *dO, const void *Wt, const void *F, const float *bias, void *dF, float *colpart, int M,
                                int N, int K, int lda, int ldw, int ldf, int lddf, gm3d_stream_t stream);
 int gm3d_gemm_tile_rows(int M);
+/* dst (batch, cols, rows) = transposes of `batch` row-major (rows, cols) bf16 matrices that start src_batch_stride elements apart
+ * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 64. */
+int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows, int cols, long long src_batch_stride,
+                                gm3d_stream_t stream);
+/* Token / positional-embedding assembly around the mask (models_mae_learn_loss.py:298-300,649-658) in one pass each way.
+ * order (B,L) int64 = [visible ids | masked ids], a permutation of 0..L-1 per sample (gm3d_mask_select writes exactly this when its
+ * two id outputs are the halves of one (B,L) buffer).  fwd: x_vis, pos_vis (B,V,C) and pos_full (B,L,C) gathered from tokens / pos
+ * (B,L,C).  bwd: dtokens, dpos (B,L,C) from dx_vis, dpos_vis (B,V,C) and dpos_full (B,L,C) (any may be NULL = zero). */
+int gm3d_token_assemble_fwd(const void *tokens, const void *pos, const long long *order, int B, int L, int V, int C, void *x_vis,
+                            void *pos_vis, void *pos_full, int dtype, gm3d_stream_t stream);
+int gm3d_token_assemble_bwd(const void *dx_vis, const void *dpos_vis, const void *dpos_full, const long long *order, int B, int L,
+                            int V, int C, void *dtokens, void *dpos, int dtype, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -115,6 +115,10 @@ def test_stacked_transpose_strided_view():
     ws = [flat[7 + i * 1000: 7 + i * 1000 + 24 * 16].view(24, 16) for i in range(5)]      # constant stride in one buffer
     out = gemm.stacked_transpose(ws)
     assert out.shape == (5, 16, 24) and all(torch.equal(out[i], ws[i].t()) for i in range(5))
+    flat = torch.randn(4 * 400000 + 16, device="cuda").bfloat16()                          # the HIP transpose kernel: dims % 64 == 0
+    ws = [flat[16 + i * 400000: 16 + i * 400000 + 384 * 640].view(384, 640) for i in range(4)]
+    out = gemm.stacked_transpose(ws)
+    assert out.shape == (4, 640, 384) and all(torch.equal(out[i], ws[i].t()) for i in range(4))
     loose = [torch.randn(24, 16, device="cuda").bfloat16() for _ in range(3)]
     out = gemm.stacked_transpose(loose)
     assert all(torch.equal(out[i], loose[i].t()) for i in range(3))

@@ -121,3 +121,32 @@ def test_mask_select_kernel(B, L, ratio, epoch):
     wv, wm = M.split_ids(want.bool(), len_keep)
     assert torch.equal(vis.cpu(), wv) and torch.equal(msk.cpu(), wm)
     assert torch.equal(m.generate_mask(lp.cuda(), ratio, epoch=epoch, total_epoch=400, noise=noise).cpu(), want)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [25, 64, 1])
+def test_token_assemble(dtype, V):
+    """TokenAssembleFn == take/cat of the module path, forward and backward (exact: pure data movement + one add)."""
+    from gm3d_amd import heads
+    from gm3d_amd import models_mae_learn_loss as M
+    B, L, C = 7, 64, 384
+    g = torch.Generator().manual_seed(V)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    for b in range(B):
+        mask[b, torch.randperm(L, generator=g)[: L - V]] = True
+    vis_ids, mask_ids = M.split_ids(mask.cuda(), V)
+    tok = torch.randn(B, L, C, generator=g).to(dtype).cuda().requires_grad_(True)
+    pos = torch.randn(B, L, C, generator=g).to(dtype).cuda().requires_grad_(True)
+    w = [torch.randn(B, V, C, generator=g).to(dtype).cuda(), torch.randn(B, V, C, generator=g).to(dtype).cuda(),
+         torch.randn(B, L, C, generator=g).to(dtype).cuda()]
+    xv, pv, pf = heads.token_assemble(tok, pos, vis_ids, mask_ids)
+    (xv * w[0]).sum().backward(retain_graph=True); (pv * w[1]).sum().backward(retain_graph=True); (pf * w[2]).sum().backward()
+    got = (xv.detach().clone(), pv.detach().clone(), pf.detach().clone(), tok.grad.clone(), pos.grad.clone())
+    tok.grad = pos.grad = None
+    rxv, rpv = M.take(tok, vis_ids), M.take(pos, vis_ids)
+    rpf = torch.cat([M.take(pos, vis_ids), M.take(pos, mask_ids)], dim=1)
+    ((rxv * w[0]).sum() + (rpv.float() * w[1].float()).sum() + (rpf.float() * w[2].float()).sum()).backward()
+    assert torch.equal(got[0], rxv) and torch.equal(got[1], rpv) and torch.equal(got[2], rpf)
+    assert torch.equal(got[3], tok.grad)
+    tol = 0.0 if dtype == torch.float32 else 2.0 ** -7 * float(pos.grad.abs().max())     # bf16: the module path sums in another order
+    assert float((got[4].float() - pos.grad.float()).abs().max()) <= tol + 1e-6

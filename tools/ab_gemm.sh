@@ -1,5 +1,5 @@
 for rep in 1 2; do
-for cfg in "GM3D_OWN_GEMM=0" "GM3D_FUSE_POOL=0 GM3D_FUSE_GELU=0" "GM3D_FUSE_GELU_BWD=0" "GM3D_FUSE_POOL=1"; do
+for cfg in "GM3D_OWN_GEMM=0" "GM3D_FUSE_POOL=0 GM3D_FUSE_GELU=0" "GM3D_FUSE_POOL=1"; do
   env $cfg python bench.py --steps 40 --warmup 5 --no-cpu-baseline 2>/dev/null | python -c "
 import json,sys;d=json.loads(sys.stdin.read().strip().splitlines()[-1]);print('$cfg', round(d['value']), round(d['ms_per_step'],3))"
 done; done
