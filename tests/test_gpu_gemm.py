@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("M,K,N", [(8192, 384, 1152), (3200, 1536, 384), (8192, 384, 1536), (3200, 384, 384), (100, 64, 128),
-                                   (129, 128, 256), (4096, 512, 384), (1, 1152, 384)])
+                                   (129, 128, 256), (4096, 512, 384), (1, 1152, 384), (8200, 384, 384), (8321, 1536, 384), (16384, 128, 256)])
 @pytest.mark.parametrize("bias", [False, True])
 def test_gemm_tn(M, K, N, bias):
     from gm3d_amd import gemm
