@@ -329,7 +329,7 @@ __global__ void group_scatter_add_kernel(T* __restrict__ df, const T* __restrict
 // The weight gradient is the small difference of these large sums, so they are accumulated and finished in
 // fp64 (full-rate on CDNA vector units; this kernel is bandwidth-bound anyway).
 template <class T>
-__global__ void pn_layer1_bwd_stats_kernel(const T* __restrict__ da1, const T* __restrict__ a1, const float* __restrict__ x,
+__global__ __launch_bounds__(256) void pn_layer1_bwd_stats_kernel(const T* __restrict__ da1, const T* __restrict__ a1, const float* __restrict__ x,
                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                            const float* __restrict__ xmean, int R, int C1, double* __restrict__ partial) {
@@ -377,10 +377,18 @@ __global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __
     __shared__ double red[8][32];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
-    double s = 0.0;
-    if (c < ncols)
-        for (int r = slice; r < nrows; r += 8) s += partial[(size_t)r * pitch + c];
-    red[slice][cx] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;      // four independent chains: the loads stream instead of serialising
+    if (c < ncols) {
+        int r = slice;
+        for (; r + 24 < nrows; r += 32) {
+            s0 += partial[(size_t)r * pitch + c];
+            s1 += partial[(size_t)(r + 8) * pitch + c];
+            s2 += partial[(size_t)(r + 16) * pitch + c];
+            s3 += partial[(size_t)(r + 24) * pitch + c];
+        }
+        for (; r < nrows; r += 8) s0 += partial[(size_t)r * pitch + c];
+    }
+    red[slice][cx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (slice == 0 && c < ncols) {
         double t = 0.0;
@@ -434,7 +442,7 @@ __global__ __launch_bounds__(256) void lin3_gelu_fwd_kernel(const float* __restr
 
 // dpre = dout * GELU'(pre); partial[block][q][c] (fp64): q=0 sum dpre (bias grad), q=1..3 sum dpre * x_j (weight grad)
 template <class T>
-__global__ void lin3_gelu_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void lin3_gelu_bwd_kernel(const T* __restrict__ dout, const float* __restrict__ x, const float* __restrict__ w,
                                      const float* __restrict__ b, int R, int C, double* __restrict__ partial) {
     extern __shared__ double smd[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
