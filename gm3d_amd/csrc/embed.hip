@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void group_max_fwd_kernel(const T* __restrict_
 
 // din[g,k,c] = (k == arg[g,c]) ? dout[g,c] : 0      (dense scatter: the GEMMs that follow want a dense operand)
 template <class T>
-__global__ void group_max_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg, T* __restrict__ din,
+__global__ __launch_bounds__(256) void group_max_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg, T* __restrict__ din,
                                      int G, int K, int C) {
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
@@ -151,7 +151,7 @@ __device__ __forceinline__ void write_partials(float (&acc)[NQ][8], float* sm, f
 
 // y = y0 + t[group]:  partial[block][0][c] = sum y, [1][c] = sum y^2
 template <class T>
-__global__ void bn_bcast_stats_kernel(const T* __restrict__ y0, const T* __restrict__ t, int G, int K, int C,
+__global__ __launch_bounds__(256) void bn_bcast_stats_kernel(const T* __restrict__ y0, const T* __restrict__ t, int G, int K, int C,
                                       float* __restrict__ partial) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
@@ -174,7 +174,7 @@ __global__ void bn_bcast_stats_kernel(const T* __restrict__ y0, const T* __restr
 
 // a2 = act((y0 + t[group]) * scale + shift), act(h) = h > 0 ? h : slope*h  (slope 0: ReLU, 0.2: the head's LeakyReLU)
 template <class T>
-__global__ void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __restrict__ t, const float* __restrict__ scale,
+__global__ __launch_bounds__(256) void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __restrict__ t, const float* __restrict__ scale,
                                            const float* __restrict__ shift, T* __restrict__ a2, int G, int K, int C,
                                            float slope) {
     const int tpr = C >> 3, SL = blockDim.x / tpr;
@@ -199,7 +199,7 @@ __global__ void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __
 // BatchNorm(+ReLU) backward, pass 1: g = da2 * [scale*y+shift > 0], yhat = (y - mean) * rstd
 //   partial[block][0][c] = sum g, [1][c] = sum g * yhat
 template <class T>
-__global__ void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
+__global__ __launch_bounds__(256) void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, int G, int K, int C,
                                           float* __restrict__ partial, float slope) {
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __rest
 // df[g, arg[g,c], c] += dfg[g,c] (the max-pool branch of the first stage), in place; partial[block][c] = column
 // sums of the resulting df (gradient of the conv bias in front of it).
 template <class T>
-__global__ void group_scatter_add_kernel(T* __restrict__ df, const T* __restrict__ dfg, const uint8_t* __restrict__ arg,
+__global__ __launch_bounds__(256) void group_scatter_add_kernel(T* __restrict__ df, const T* __restrict__ dfg, const uint8_t* __restrict__ arg,
                                          int G, int K, int C, float* __restrict__ partial) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __
 
 // Generic column partial sums of a (R,C) matrix: partial[block][c]
 template <class T>
-__global__ void colsum_partial_kernel(const T* __restrict__ m, int R, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ m, int R, int C, float* __restrict__ partial) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
