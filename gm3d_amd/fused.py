@@ -188,6 +188,30 @@ def _wgrad_batched(dy, x):
     """dW[i] = dy[i]^T @ x[i] for every block of a stack in ONE batched GEMM, fp32 result.
     (K = rows is 3200..8192 and the output is only 384..1536 wide: a single such GEMM fills a fraction of the
     256 CUs -- 50 us each through hipBLASLt -- while the batch over blocks runs at ~16 us per block.)"""
+    nblk, R, N = dy.shape
+    K = x.shape[2]
+    S = WGRAD_ROW_SPLIT
+    if S == 0:      # auto: the smallest split that gives the chip >= 512 output tiles of 128x128 while keeping >= 512 rows each
+        S, tiles = 1, nblk * max(N // 128, 1) * max(K // 128, 1)
+        while tiles * S < 512 and S < 8 and R % (2 * S) == 0 and R // (2 * S) >= 512:
+            S *= 2
+    elif nblk > 4 or R // S < 1024:
+        S = 1
+    if S > 1 and R % S == 0 and dy.is_contiguous() and x.is_contiguous():
+        # few blocks (the 4-block decoders): nblk * (N/128) * (K/128) tiles do not fill 256 CUs and each runs an 8192-deep
+        # reduction -- split the rows S ways into more batches and add the S partial products with the two-stage sum
+        part = _wgrad_batched_plain(dy.view(nblk * S, R // S, N), x.view(nblk * S, R // S, K))
+        out = torch.empty(nblk, N, K, dtype=torch.float32, device=dy.device)
+        _launch("gm3d_colsum_finish_batched", {"rows": nblk * S, "cols": N * K}, lib.gm3d_colsum_finish_batched, _ptr(part), nblk,
+                S * N * K, S, N * K, N * K, _ptr(out), N * K, _stream())
+        return out
+    return _wgrad_batched_plain(dy, x)
+
+
+WGRAD_ROW_SPLIT = int(__import__("os").environ.get("GM3D_WGRAD_SPLIT", "4"))   # 0 = auto, 1 = off, n = fixed n-way for <=4-block stacks
+
+
+def _wgrad_batched_plain(dy, x):
     if dy.dtype == torch.float32:
         return torch.bmm(dy.transpose(1, 2), x)
     try:
