@@ -16,8 +16,8 @@
 // permuted by the C layout).  Two precisions share the structure:
 //   GM3D_BF16: v_mfma_f32_32x32x16_bf16, f32 softmax and accumulation (throughput mode);
 //   GM3D_F32 : v_mfma_f32_32x32x2_f32, bit-exact f32 FMA chains (parity mode).
-// Backward recomputes P from the saved log-sum-exp; each wave owns one 32-key tile for
-// dK/dV and one 32-query tile for dQ, so there are no atomics and no cross-workgroup sums.
+// Backward recomputes P from the saved log-sum-exp; NT waves each own one 32-key tile (dK/dV) and NT more waves each own
+// one 32-query tile (dQ), side by side in the same workgroup: no atomics, no cross-workgroup sums.
 // Kernels are templated on MT, the number of 32-row tiles the LDS buffers hold (2: T <= 64, 4: T <= 128).
 #include "common.hpp"
 
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * MT) void attn_fwd_f32_kernel(const float* __re
 // ===================================================================== backward, bf16
 // LDS (dynamic): Q,K,V,dO tiles (ROWS x VLD bf16 each) + lse[ROWS] + delta[ROWS].
 template <int MT>
-__global__ __launch_bounds__(64 * MT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+__global__ __launch_bounds__(128 * MT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -296,8 +296,10 @@ __global__ __launch_bounds__(64 * MT) void attn_bwd_bf16_kernel(const bf16_t* __
     bf16_t* dKg = dQg + os;
     bf16_t* dVg = dKg + os;
 
-    // ---- phase A: this wave owns key tile kt = w.  Tiles X[q][key]: rows = q (regs), cols = key (lanes).
-    {
+    // The workgroup has 2*NT waves: waves 0..NT-1 each own one key tile (phase A: dK, dV), waves NT..2NT-1 each own one query
+    // tile (phase B: dQ) -- the two phases of a (b,h) problem run side by side instead of one after the other.
+    // ---- phase A: this wave owns key tile kt.  Tiles X[q][key]: rows = q (regs), cols = key (lanes).
+    if (w < NT) {
         const int kt = w;
         const int key = 32 * kt + r;
         f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
@@ -337,9 +339,9 @@ __global__ __launch_bounds__(64 * MT) void attn_bwd_bf16_kernel(const bf16_t* __
             }
         }
     }
-    // ---- phase B: this wave owns query tile qt = w.  Tiles X'[key][q]: rows = key (regs), cols = q (lanes).
-    {
-        const int qt = w;
+    // ---- phase B: this wave owns query tile qt.  Tiles X'[key][q]: rows = key (regs), cols = q (lanes).
+    else {
+        const int qt = w - NT;
         const int q = 32 * qt + r;
         const float lq = Ls[q], dq_ = Del[q];
         f32x16 dq0 = zero16(), dq1 = zero16();
@@ -377,7 +379,7 @@ __global__ __launch_bounds__(64 * MT) void attn_bwd_bf16_kernel(const bf16_t* __
 
 // ===================================================================== backward, f32
 template <int MT>
-__global__ __launch_bounds__(64 * MT) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+__global__ __launch_bounds__(128 * MT) void attn_bwd_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ dout, const float* __restrict__ lse,
                                                                float* __restrict__ dqkv, int T, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -418,7 +420,7 @@ __global__ __launch_bounds__(64 * MT) void attn_bwd_f32_kernel(const float* __re
     float* dKg = dQg + os;
     float* dVg = dKg + os;
 
-    {   // phase A: key tile kt = w; X[q][key]
+    if (w < NT) {   // phase A (waves 0..NT-1): key tile kt; X[q][key]
         const int kt = w;
         const int key = 32 * kt + r;
         f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
@@ -456,8 +458,8 @@ __global__ __launch_bounds__(64 * MT) void attn_bwd_f32_kernel(const float* __re
             }
         }
     }
-    {   // phase B: query tile qt = w; X'[key][q]
-        const int qt = w;
+    else {   // phase B (waves NT..2NT-1): query tile qt; X'[key][q]
+        const int qt = w - NT;
         const int q = 32 * qt + r;
         const float lq = Ls[q], dq_ = Del[q];
         f32x16 dq0 = zero16(), dq1 = zero16();
@@ -537,7 +539,7 @@ extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* 
     if (!dout || !lse || !dqkv) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int threads = 64 * ((T + 31) / 32);
+    const int threads = 128 * ((T + 31) / 32);   // NT key-tile waves + NT query-tile waves
     const int rows = T <= 64 ? 64 : 128;
     if (dtype == GM3D_BF16) {
         const size_t lds = (size_t)4 * rows * VLD * sizeof(bf16_t) + 2 * rows * sizeof(float);
