@@ -368,6 +368,24 @@ __global__ __launch_bounds__(256) void colsum_finish_batched_kernel(const float*
     }
 }
 
+// Few rows, very many columns (the S-way row-split weight gradients: S x (N*K) partial products per block): out[j][c] =
+// sum_r partial[j][r][c], 16 bytes per lane per row, all S loads of a thread in flight.
+__global__ __launch_bounds__(256) void sum_few_rows_kernel(const float* __restrict__ partial, int nrows, size_t ncols4,
+                                                           float* __restrict__ out) {
+    const size_t job = blockIdx.y;
+    const float4* p = reinterpret_cast<const float4*>(partial) + job * nrows * ncols4;
+    float4* o = reinterpret_cast<float4*>(out) + job * ncols4;
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < ncols4; c += (size_t)gridDim.x * 256) {
+        float4 a = p[c];
+#pragma unroll 8
+        for (int r = 1; r < nrows; ++r) {
+            const float4 b = p[(size_t)r * ncols4 + c];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        o[c] = a;
+    }
+}
+
 static inline int ln_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 512 ? 512 : g); }
 static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
 static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
@@ -474,6 +492,17 @@ extern "C" int gm3d_colsum_finish_batched(const float* partial, int njobs, long 
     if (njobs > 65535) return GM3D_EUNSUPPORTED;
     hipLaunchKernelGGL(colsum_finish_batched_kernel, dim3((ncols + 31) / 32, njobs), dim3(256), 0, (hipStream_t)stream, partial,
                        (size_t)job_stride, nrows, pitch, ncols, out, out_stride);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_sum_few_rows(const float* partial, int njobs, int nrows, long long ncols, float* out, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!partial || !out || njobs < 1 || nrows < 1 || ncols < 4) return GM3D_EINVAL;
+    if (ncols % 4 || njobs > 65535 || nrows > 64) return GM3D_EUNSUPPORTED;
+    const size_t n4 = (size_t)ncols / 4;
+    int gx = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(sum_few_rows_kernel, dim3(gx, njobs), dim3(256), 0, (hipStream_t)stream, partial, nrows, n4, out);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -54,7 +54,12 @@ def splitk_wgrad(dy, x):
             part = torch.bmm(a, b).float()
     if S == 1:
         return part[0]
-    return _finish(part.view(S, N * K), S, N * K).view(N, K)
+    from . import fused
+    if not fused.SUM_FEW_ROWS:
+        return _finish(part.view(S, N * K), S, N * K).view(N, K)
+    out = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+    _launch("gm3d_sum_few_rows", {"rows": S, "cols": N * K}, lib.gm3d_sum_few_rows, _ptr(part), 1, S, N * K, _ptr(out), _stream())
+    return out
 
 
 def _c32(p):

@@ -202,12 +202,17 @@ def _wgrad_batched(dy, x):
         # reduction -- split the rows S ways into more batches and add the S partial products with the two-stage sum
         part = _wgrad_batched_plain(dy.view(nblk * S, R // S, N), x.view(nblk * S, R // S, K))
         out = torch.empty(nblk, N, K, dtype=torch.float32, device=dy.device)
-        _launch("gm3d_colsum_finish_batched", {"rows": nblk * S, "cols": N * K}, lib.gm3d_colsum_finish_batched, _ptr(part), nblk,
-                S * N * K, S, N * K, N * K, _ptr(out), N * K, _stream())
+        if SUM_FEW_ROWS:
+            _launch("gm3d_sum_few_rows", {"rows": nblk * S, "cols": N * K}, lib.gm3d_sum_few_rows, _ptr(part), nblk, S, N * K,
+                    _ptr(out), _stream())
+        else:
+            _launch("gm3d_colsum_finish_batched", {"rows": nblk * S, "cols": N * K}, lib.gm3d_colsum_finish_batched, _ptr(part), nblk,
+                    S * N * K, S, N * K, N * K, _ptr(out), N * K, _stream())
         return out
     return _wgrad_batched_plain(dy, x)
 
 
+SUM_FEW_ROWS = __import__("os").environ.get("GM3D_SUM_FEW_ROWS", "1") == "1"
 WGRAD_ROW_SPLIT = int(__import__("os").environ.get("GM3D_WGRAD_SPLIT", "4"))   # 0 = auto, 1 = off, n = fixed n-way for <=4-block stacks
 
 

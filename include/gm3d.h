@@ -295,6 +295,9 @@ int gm3d_token_assemble_fwd(const void *tokens, const void *pos, const long long
                             void *pos_vis, void *pos_full, int dtype, gm3d_stream_t stream);
 int gm3d_token_assemble_bwd(const void *dx_vis, const void *dpos_vis, const void *dpos_full, const long long *order, int B, int L,
                             int V, int C, void *dtokens, void *dpos, int dtype, gm3d_stream_t stream);
+/* out (njobs, ncols) f32 = sum over the nrows (<= 64) rows of each job of partial (njobs, nrows, ncols): the S-way row-split
+ * weight-gradient partial products.  ncols % 4 == 0. */
+int gm3d_sum_few_rows(const float *partial, int njobs, int nrows, long long ncols, float *out, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }
