@@ -173,7 +173,10 @@ def main():
     model = M.mae_vit_base_patch16_dec512d8b(norm_pix_loss=False).to(device).train()
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
     use_graph = not args.no_graph
-    optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=model_ema)
+    # data-parallel: lay the flat gradient buffer out by backward segment so that each segment is one all-reduce range
+    segmented = use_dist and os.environ.get("GM3D_DDP_SEGMENTED", "1") == "1" and not args.no_graph
+    optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=model_ema,
+                                  segment_of=E.ddp_segment if segmented else None)
     grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=args.bucket_mb << 20) if use_dist else None
     step_args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=not args.fp32, accum_iter=1,
                                 lr=1e-3, min_lr=0.0, warmup_epochs=40)
@@ -204,7 +207,22 @@ def main():
     dominant = max((n for n in psum if algorithmic(n, psum[n]["meta"])), key=lambda n: psum[n]["total_ms"])
 
     graph_note = None
-    if use_graph:
+    seg_note = None
+    if use_graph and segmented:
+        # four graphs with the all-reduce of each backward segment issued while the next segment runs (SegmentedDDPStep);
+        # any problem falls back to the two-graph layout below
+        try:
+            graphed = E.SegmentedDDPStep(model, model_ema, optimizer, step_args, pool[0], args.epoch)
+        except Exception as ex:
+            seg_note = "segmented capture failed (%s: %s)" % (type(ex).__name__, str(ex)[:120])
+            segmented = False
+    else:
+        segmented = False
+    if use_dist and use_graph:    # every rank must take the same layout
+        flag = torch.tensor([1.0 if segmented else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        segmented = segmented and float(flag) == 1.0
+    if use_graph and not segmented:
         try:
             graphed = E.GraphedPretrainStep(model, model_ema, optimizer, step_args, pool[0], args.epoch, grad_sync=grad_sync)
         except Exception as ex:  # never lose the measurement to a capture problem: fall back to eager launches
@@ -312,8 +330,10 @@ def main():
                          "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype, [m for _, m in tsum["per_launch"]]),
                          "avg_launch_us": raw_avg_ms * 1e3, "empty_bracket_us": overhead_ms * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
-            "execution": ("hipGraph replay" + (" (fwd+bwd | all-reduce | update)" if use_dist else "")) if use_graph
+            "execution": ("hipGraph replay" + ((" (4 graphs: segment all-reduces overlap the next backward segment)" if segmented else
+                                             " (fwd+bwd | all-reduce | update)") if use_dist else "")) if use_graph
             else (graph_note or "eager"),
+            "execution_note": seg_note,
             "kernel_rooflines": all_roof,
             "tuned_gemm_table": bool(tuned),
             "hip_kernels_ms_per_step": per_step,

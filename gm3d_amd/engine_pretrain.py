@@ -96,14 +96,24 @@ def add_weight_decay(model, weight_decay=1e-5, skip_list=()):
     return [{"params": no_decay, "weight_decay": 0.0}, {"params": decay, "weight_decay": weight_decay}]
 
 
+def ddp_segment(name):
+    """Backward segment of a parameter of MaskedAutoencoderViT, in the order backward completes them: 0 = decoders, heads and
+    mask token; 1 = the 12-block encoder stack (+ norm_p); 2 = token embed and positional embed."""
+    if name.startswith("blocks.") or name.startswith("norm_p."):
+        return 1
+    if name.startswith("encoder.") or name.startswith("pos_embed."):
+        return 2
+    return 0
+
+
 def build_optimizer(model, lr=1e-3, weight_decay=0.05, fused=True, capturable=False, flat=False, model_ema=None,
-                    clip_grad=5.0):
+                    clip_grad=5.0, segment_of=None):
     """flat=True: FlatAdamWEma (gm3d_amd/optim.py) -- clip + AdamW + EMA + bf16 shadows in one pass over flat buffers;
     pass the ModelEma so the teacher's parameters join the layout.  Otherwise torch.optim.AdamW with the reference's
     parameter groups."""
     if flat:
         from .optim import FlatAdamWEma
-        return FlatAdamWEma(model, model_ema, lr=lr, weight_decay=weight_decay, max_norm=clip_grad)
+        return FlatAdamWEma(model, model_ema, lr=lr, weight_decay=weight_decay, max_norm=clip_grad, segment_of=segment_of)
     groups = add_weight_decay(model, weight_decay=weight_decay)
     kw = {}
     if fused and next(model.parameters()).is_cuda:
@@ -273,16 +283,18 @@ class GradSync:
 
 def broadcast_buffers(model, src=0, group=None):
     """DDP's default broadcast_buffers=True: rank 0's BatchNorm running statistics overwrite the other
-    ranks' before the forward pass; one coalesced collective."""
+    ranks' before the forward pass; one coalesced collective (3 launches: pack, broadcast, unpack)."""
     bufs = [b for b in model.buffers() if b.dtype.is_floating_point]
     if not bufs or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     flat = torch.cat([b.reshape(-1) for b in bufs])
     dist.broadcast(flat, src=src, group=group)
-    off = 0
+    views, off = [], 0
     for b in bufs:
-        b.copy_(flat[off:off + b.numel()].view_as(b))
+        views.append(flat[off:off + b.numel()].view_as(b))
         off += b.numel()
+    with torch.no_grad():
+        torch._foreach_copy_(bufs, views)
 
 
 def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
@@ -479,10 +491,188 @@ class GraphedPretrainStep:
         self.static_in.copy_(samples, non_blocking=True)
         if self.static_noise is not None:
             self.static_noise.copy_(mask_noise, non_blocking=True)
+        if self.graph2 is not None:
+            broadcast_buffers(self.model.module if hasattr(self.model, "module") else self.model)   # like DDP, every forward
         self.graph.replay()
         if self.graph2 is not None:
             self.grad_sync.finish()
             self.graph2.replay()
+        return self.out
+
+
+class SegmentedDDPStep:
+    """Data-parallel pretrain step with the gradient all-reduce hidden behind backward, as FOUR hipGraphs with eager RCCL
+    collectives between them (no collective is captured):
+
+        graph 1  forward + backward of losses, heads and both decoders   -> all-reduce (async) of segment 0's gradients
+        graph 2  backward of the 12-block encoder stack                  -> all-reduce (async) of segment 1's gradients
+        graph 3  backward of token embed + positional embed              -> all-reduce of segment 2 (+ every non-decayed
+                                                                            parameter: biases, norms, tokens)
+        graph 4  clip + AdamW + EMA (after the collectives)
+
+    The backward is cut with torch.autograd.grad at the tensors where the segments meet (x_vis / pos_full: encoder output and
+    decoder positions; tokens / pos_all: embed outputs), so the sum of the three partial backwards is exactly the single
+    backward -- tests/test_gpu_graph.py checks it against the un-segmented step.  Needs FlatAdamWEma built with
+    segment_of=ddp_segment: each segment's weight gradients are one contiguous range of the flat buffer.
+    While graph 2 runs, RCCL's stream reduces segment 0 (57 MB); while graph 3 runs, segment 1 (85 MB); only segment 2's
+    ~5 MB collective is exposed."""
+
+    def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3, augment=True, inject_mask_noise=False,
+                 process_group=None, use_graphs=True):
+        assert getattr(optimizer, "segment_ranges", None) is not None, "build the optimizer with segment_of=ddp_segment"
+        self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
+        self.raw = model.module if hasattr(model, "module") else model
+        self.group, self.augment = process_group, augment
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        L = self.raw.num_group
+        self.static_in = example.clone()
+        self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
+        views = dict((id(p), g) for p, g in optimizer.flat_grad_views())
+        self.seg_params = {sg: [p for p in ps] for sg, ps in optimizer.segment_params.items()}
+        self.seg_views = {sg: [views[id(p)] for p in ps] for sg, ps in self.seg_params.items()}
+        self.use_graphs = use_graphs
+        self.graphs = None
+        if use_graphs:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup_iters):
+                    self._eager(self.static_in.clone())
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            import os
+            mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
+            self.graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
+            with torch.cuda.graph(self.graphs[0], capture_error_mode=mode):
+                self.out = self._phase1(self.static_in)
+            for k, phase in ((1, self._phase2), (2, self._phase3)):
+                with torch.cuda.graph(self.graphs[k], pool=self.graphs[0].pool(), capture_error_mode=mode):
+                    phase()
+            with torch.cuda.graph(self.graphs[3], pool=self.graphs[0].pool(), capture_error_mode=mode):
+                self.out["grad_norm"] = step_update(model, model_ema, optimizer)
+
+    # ---- the three backward segments --------------------------------------------------------------------------------
+    def _store(self, seg, grads):
+        """gradients of one segment -> their slots of the flat buffer (ONE multi-tensor copy; unused parameters: zeros)."""
+        views, have, zero = self.seg_views[seg], [], []
+        for v, g in zip(views, grads):
+            (have if g is not None else zero).append((v, g))
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if zero:
+            torch._foreach_zero_([v for v, _ in zero])
+
+    def _phase1(self, samples):
+        raw, teacher, args, epoch = self.raw, self.ema.ema, self.args, self.epoch
+        self.opt.zero_grad(set_to_none=True)       # no stale p.grad may be gathered over the segment gradients by step()
+        L = raw.num_group
+        len_keep = int(L * (1 - args.mask_ratio))
+        if self.augment:
+            samples = train_transforms(samples)
+        bf16 = getattr(args, "bf16", False)
+        if bf16:
+            from .fused import weight_cache
+            weight_cache.pin(raw)
+            weight_cache.pin(teacher)
+            weight_cache.refresh()
+        amp = torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()
+        B = samples.shape[0]
+        visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
+        with amp:
+            with torch.no_grad():
+                group = teacher.group_divider(samples)
+                all_ids = (_arange_ids(B, L, samples.device), _arange_ids(B, 0, samples.device))
+                outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False, ids=all_ids)
+                mask, vis_ids, mask_ids = teacher.generate_mask_ids(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True,
+                                                                    epoch=epoch, total_epoch=args.epochs, noise=self.static_noise)
+                bool_masked_pos = mask.flatten(1).to(torch.bool)
+            tokens = raw.encoder(group[0])                    # segment 2 | segment 1 boundary: the encoder sees detached leaves
+            pos_all = raw.embed_pos(group[1])
+            tokens_d, pos_all_d = tokens.detach().requires_grad_(True), pos_all.detach().requires_grad_(True)
+            outs = self.model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens_d, pos_all=pos_all_d,
+                              ids=(vis_ids, mask_ids), cut=True)
+            M = outs["mask_num"]
+            loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"], mask_ids=mask_ids)
+            loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
+            loss = 13.889 * loss_mse + 1.0 * loss_chfr
+            loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos, loss_outs["matrix"].detach(),
+                                                   relative=args.relative)
+        total = (loss + loss_learn) / getattr(args, "accum_iter", 1)
+        x_vis_d, pos_full_d = outs["features"], outs["pos_full"]   # segment 1 | segment 0 boundary (detached leaves)
+        p0 = self.seg_params[0]
+        g = torch.autograd.grad(total, p0 + [x_vis_d, pos_full_d], allow_unused=True)
+        self._store(0, g[:len(p0)])
+        self._cut1 = outs["cut"] + (g[len(p0)], g[len(p0) + 1])
+        self._cut2 = (tokens, pos_all, tokens_d, pos_all_d)
+        return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
+                "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
+                "teacher_loss_pred": outs_ema["loss_pred"]}
+
+    def _phase2(self):
+        x_vis, pos_full, gx, gp = self._cut1
+        tokens_d, pos_all_d = self._cut2[2], self._cut2[3]
+        p1 = self.seg_params[1]
+        outs = [t for t, gt in ((x_vis, gx), (pos_full, gp)) if gt is not None]
+        gouts = [gt for gt in (gx, gp) if gt is not None]
+        g = torch.autograd.grad(outs, p1 + [tokens_d, pos_all_d], grad_outputs=gouts, allow_unused=True)
+        self._store(1, g[:len(p1)])
+        self._cut3 = (g[len(p1)], g[len(p1) + 1])
+
+    def _phase3(self):
+        tokens, pos_all = self._cut2[0], self._cut2[1]
+        gt, gp = self._cut3
+        p2 = self.seg_params[2]
+        outs = [t for t, q in ((tokens, gt), (pos_all, gp)) if q is not None]
+        gouts = [q for q in (gt, gp) if q is not None]
+        g = torch.autograd.grad(outs, p2, grad_outputs=gouts, allow_unused=True)
+        self._store(2, g)
+
+    def _reduce(self, seg):
+        """async all-reduce (mean) of one segment's range of the flat gradient buffer on the process group's stream."""
+        if not dist.is_initialized():
+            return None
+        lo, hi = self.opt.segment_ranges[seg]
+        buf = self.opt.G[lo:hi]
+        w = dist.all_reduce(buf, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM, group=self.group, async_op=True)
+        return (w, buf)
+
+    def _wait(self, works):
+        for item in works:
+            if item is None:
+                continue
+            w, buf = item
+            w.wait()
+            if not self._avg:
+                buf.div_(self.world)
+
+    def _eager(self, samples):
+        out = self._phase1(samples)
+        works = [self._reduce(0)]
+        self._phase2()
+        works.append(self._reduce(1))
+        self._phase3()
+        works.append(self._reduce(2))
+        self._wait(works)
+        self._cut1 = self._cut2 = self._cut3 = None      # eager: let the autograd graph go (captured graphs keep theirs alive)
+        out["grad_norm"] = step_update(self.model, self.ema, self.opt)
+        return out
+
+    def __call__(self, samples, mask_noise=None):
+        if self.graphs is None:
+            if self.static_noise is not None:
+                self.static_noise.copy_(mask_noise, non_blocking=True)
+            return self._eager(samples)
+        self.static_in.copy_(samples, non_blocking=True)
+        if self.static_noise is not None:
+            self.static_noise.copy_(mask_noise, non_blocking=True)
+        broadcast_buffers(self.raw, group=self.group)      # DDP's per-forward BatchNorm-buffer broadcast from rank 0
+        works = []
+        for k in range(3):
+            self.graphs[k].replay()
+            works.append(self._reduce(k))
+        self._wait(works)
+        self.graphs[3].replay()
         return self.out
 
 

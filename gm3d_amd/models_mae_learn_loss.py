@@ -348,7 +348,7 @@ class MaskedAutoencoderViT(nn.Module):
         return (F.linear(h, w.unsqueeze(0)).squeeze(-1) + c1.bias.mean()).view(B, L)
 
     def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True, tokens=None,
-                pos_all=None, ids=None):
+                pos_all=None, ids=None, cut=False):
         """pts (B,N,3) f32, mask (B,64) bool (True = masked).  Extra keyword-only conveniences for the
         engine: `num_visible` (static visible count, avoids a host sync), `group` (a previously
         computed (neighborhood, center, neighborhood_org), e.g. the teacher's -- the student sees the
@@ -372,6 +372,15 @@ class MaskedAutoencoderViT(nn.Module):
         B, _, C = x_vis.shape
         if noaug:
             return x_vis
+        cut_pair = None
+        if cut:
+            # segmented backward (engine_pretrain.SegmentedDDPStep): the decoders see detached leaves, so that the backward of
+            # "losses + heads + decoders" is a closed autograd graph ending at (x_vis, pos_full); their gradients are fed into
+            # the encoder's graph by the engine.  (Asking autograd for the gradient of the un-detached tensors would make it run
+            # the encoder's backward as well: the node that produced pos_full also consumes the encoder's input gradients.)
+            cut_pair = (x_vis, pos_full)
+            x_vis = x_vis.detach().requires_grad_(True)
+            pos_full = pos_full.detach().requires_grad_(True) if pos_full is not None else None
         N = mask_ids.shape[1]
         if FUSED_HEADS and x_vis.is_cuda:
             from . import heads
@@ -412,6 +421,8 @@ class MaskedAutoencoderViT(nn.Module):
             "pix_pred": rebuild_points,
             "mask": mask,
             "mask_num": N,
+            "pos_full": pos_full,       # not in the reference dict: the segmented data-parallel backward cuts the graph here
+            "cut": cut_pair,            # (x_vis, pos_full) before the cut when cut=True ("features" / "pos_full" are the leaves)
             "features": x_vis,
             "loss_pred": self._loss_pred_head(loss_pred_),
             "neighborhood": neighborhood,

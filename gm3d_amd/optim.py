@@ -15,18 +15,26 @@ from ._capi import check, lib
 from .ops import _ptr, _stream
 
 
-def _split_decay(model):
+def _split_decay(model, segment_of=None):
     decay, no_decay = [], []
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
         (no_decay if (len(p.shape) == 1 or name.endswith(".bias") or "token" in name) else decay).append((name, p))
+    if segment_of is not None:      # stable: parameters keep their order inside a segment
+        decay.sort(key=lambda kv: segment_of(kv[0]))
+        no_decay.sort(key=lambda kv: segment_of(kv[0]))
     return decay, no_decay
 
 
 class FlatAdamWEma(torch.optim.Optimizer):
-    def __init__(self, model, model_ema=None, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0):
-        decay, no_decay = _split_decay(model)
+    def __init__(self, model, model_ema=None, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0,
+                 segment_of=None):
+        """segment_of(name) -> int (optional): lay the decayed parameters out segment by segment (ascending), so that the
+        gradients of one backward segment form ONE contiguous range of the flat buffer (`segment_ranges`: data-parallel runs
+        all-reduce a segment's range while the next segment's backward is still running).  All non-decayed parameters (biases,
+        LayerNorm / BatchNorm affine, tokens: <1 % of the bytes) follow the last segment and travel with it."""
+        decay, no_decay = _split_decay(model, segment_of)
         named = decay + no_decay
         params = [p for _, p in named]
         dev = params[0].device
@@ -83,6 +91,15 @@ class FlatAdamWEma(torch.optim.Optimizer):
             self.state[p] = {"step": self.step_dev, "exp_avg": self.M[o:o + p.numel()].view_as(p),
                              "exp_avg_sq": self.V[o:o + p.numel()].view_as(p)}
         self._params, self._offs, self._named = params, offs, named
+        self.segment_ranges = None
+        if segment_of is not None:
+            segs = sorted({segment_of(n) for n, _ in decay})
+            starts = {}
+            for (n, _), o in zip(decay, offs):
+                starts.setdefault(segment_of(n), o)
+            bounds = [starts[sg] for sg in segs] + [self.n]
+            self.segment_ranges = {sg: (bounds[i], bounds[i + 1] if i + 1 < len(segs) else self.n) for i, sg in enumerate(segs)}
+            self.segment_params = {sg: [p for n, p in named if segment_of(n) == sg] for sg in segs}
         self._register_shadows(model, model_ema)
 
     def _register_shadows(self, model, model_ema):

@@ -110,3 +110,64 @@ def test_two_graph_data_parallel_path_on_one_gpu():
     for a, b in zip(res["graph"], res["eager"]):
         for x, y in zip(a, b):
             assert x == x and abs(x - y) <= 2e-2 * abs(y), res
+
+
+@pytest.mark.parametrize("use_graphs", [False, True])
+def test_segmented_ddp_step_equals_single_backward(use_graphs):
+    """SegmentedDDPStep (three autograd segments, gradients stored per segment into the segment-ordered flat buffer, the
+    collectives between them skipped without a process group) against the ordinary step on the same inputs: same losses, same
+    gradient norm, same parameters after every step."""
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import models_mae_learn_loss as M
+    from tests import clouds
+    B, steps = 8, 4
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
+    pool = [clouds.gaussian(B, 1024, 70 + i).cuda() for i in range(3)]
+    noise = [torch.rand(B, 64, generator=torch.Generator().manual_seed(100 + i)).cuda() for i in range(steps + 3)]
+
+    def build(segmented):
+        torch.manual_seed(0)
+        m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+        for mod in m.modules():
+            if isinstance(mod, M.DropPath):
+                mod.drop_prob = 0.0
+        ema = E.ModelEma(m, 0.999)
+        opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment if segmented else None)
+        return m, ema, opt
+
+    m, ema, opt = build(False)
+    ref = []
+    for i in range(steps + 3):
+        o = E.pretrain_step(m, ema, opt, pool[i % 3].clone(), 200, args, mask_noise=noise[i], augment=False)
+        ref.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+    ref_params = {k: v.detach().clone() for k, v in m.named_parameters()}
+
+    m2, ema2, opt2 = build(True)
+    rng = opt2.segment_ranges
+    assert sorted(rng) == [0, 1, 2] and rng[0][0] == 0 and rng[0][1] == rng[1][0] and rng[1][1] == rng[2][0] and rng[2][1] == opt2.n
+    got = []
+    if use_graphs:
+        # the constructor's three warm-up iterations must see the same inputs as the reference's first three steps
+        seg = E.SegmentedDDPStep.__new__(E.SegmentedDDPStep)
+        E.SegmentedDDPStep.__init__(seg, m2, ema2, opt2, args, pool[0], 200, warmup_iters=0, augment=False, inject_mask_noise=True,
+                                    use_graphs=False)
+        for i in range(3):
+            o = seg(pool[i % 3].clone(), noise[i])
+            got.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+        seg = E.SegmentedDDPStep(m2, ema2, opt2, args, pool[0], 200, warmup_iters=0, augment=False, inject_mask_noise=True,
+                                 use_graphs=True)
+        start = 3
+    else:
+        seg = E.SegmentedDDPStep(m2, ema2, opt2, args, pool[0], 200, warmup_iters=0, augment=False, inject_mask_noise=True,
+                                 use_graphs=False)
+        start = 0
+    for i in range(start, steps + 3):
+        o = seg(pool[i % 3].clone(), noise[i])
+        torch.cuda.synchronize()
+        got.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, ref)
+    worst = max(float((p.detach().float() - ref_params[k].float()).abs().max() / ref_params[k].float().abs().max().clamp_min(1e-3))
+                for k, p in m2.named_parameters())
+    assert worst <= 2e-2, worst
