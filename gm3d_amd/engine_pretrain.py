@@ -491,7 +491,7 @@ class GraphedPretrainStep:
         self.static_in.copy_(samples, non_blocking=True)
         if self.static_noise is not None:
             self.static_noise.copy_(mask_noise, non_blocking=True)
-        if self.graph2 is not None:
+        if self.graph2 is not None and getattr(self, "model", None) is not None:
             broadcast_buffers(self.model.module if hasattr(self.model, "module") else self.model)   # like DDP, every forward
         self.graph.replay()
         if self.graph2 is not None:

@@ -171,3 +171,46 @@ def test_segmented_ddp_step_equals_single_backward(use_graphs):
     worst = max(float((p.detach().float() - ref_params[k].float()).abs().max() / ref_params[k].float().abs().max().clamp_min(1e-3))
                 for k, p in m2.named_parameters())
     assert worst <= 2e-2, worst
+
+
+def test_segmented_ddp_step_through_rccl_group_of_one():
+    """The same step with a real process group (backend nccl = RCCL, world size 1): the three async all-reduces, their waits and
+    the per-step buffer broadcast are issued between the graphs; a one-rank mean all-reduce is the identity, so the trajectory
+    must equal the group-less run."""
+    import os
+    import torch.distributed as dist
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import models_mae_learn_loss as M
+    from tests import clouds
+    B = 8
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
+    pool = [clouds.gaussian(B, 1024, 170 + i).cuda() for i in range(2)]
+    noise = [torch.rand(B, 64, generator=torch.Generator().manual_seed(200 + i)).cuda() for i in range(4)]
+
+    def run():
+        torch.manual_seed(0)
+        m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+        for mod in m.modules():
+            if isinstance(mod, M.DropPath):
+                mod.drop_prob = 0.0
+        ema = E.ModelEma(m, 0.999)
+        opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment)
+        seg = E.SegmentedDDPStep(m, ema, opt, args, pool[0], 200, warmup_iters=0, augment=False, inject_mask_noise=True)
+        out = []
+        for i in range(4):
+            o = seg(pool[i % 2].clone(), noise[i])
+            torch.cuda.synchronize()
+            out.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+        return out
+
+    ref = run()
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        got = run()
+    finally:
+        dist.destroy_process_group()
+    for a, b in zip(got, ref):
+        for x, y in zip(a, b):
+            assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, ref)
