@@ -12,6 +12,7 @@
 // (lanes = rows of C, registers = 4 consecutive columns) and an LDS-staged epilogue that adds the bias in fp32 and
 // writes 16-byte row-contiguous pieces.
 #include "common.hpp"
+#include <stdlib.h>
 
 namespace gm3d {
 
@@ -23,7 +24,10 @@ constexpr int GPITCH = 72;                     // bf16 elements per LDS row (64 
 constexpr int GCP = 132;                       // floats per row of the fp32 epilogue tile
 constexpr int GSTAGE = (GBM + GBN) * GPITCH;   // bf16 elements per stage
 
-template <int KTT>   // K / 64 when it is one of the path's values (fully unrolled: exact s_waitcnt counts), 0 = run-time loop
+// KTT: K / 64 when it is one of the path's values (fully unrolled: exact s_waitcnt counts), 0 = run-time loop.
+// WMI: 32-row MFMA tiles per wave in M -- 2: 128x128 workgroup tile; 1: 64x128 (the 3200-row token streams, where 128-row tiles
+// leave 40 % of the workgroup slots empty)
+template <int KTT, int WMI>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ C, int M,
                                                               int N, int K, int lda, int ldw, int ldc, int tiles_n,
@@ -42,43 +46,47 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
     if (logical >= total_tiles) return;
     const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
-    const int m0 = tile_m * GBM, n0 = tile_n * GBN;
-    const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+    constexpr int BM = 64 * WMI, ACH = 2 * WMI;           // tile rows; 16-byte A chunks per thread per stage
+    constexpr int STAGE = (BM + GBN) * GPITCH;
+    const int m0 = tile_m * BM, n0 = tile_n * GBN;
+    const int wm = (w >> 1) * 32 * WMI, wn = (w & 1) * 64;
 
     // global -> register prefetch, TWO stages deep: 4 chunks of A and 4 of W per thread per stage (16 bytes each), two register
     // sets.  Iteration kt issues the loads of stage kt+2, multiplies stage kt, and only then parks stage kt+1 (issued one
     // iteration ago) in the LDS buffer that stage kt-1 vacated: a load has a whole iteration plus a multiply to arrive.
-    gbf16x8 pa[2][4], pw[2][4];
+    gbf16x8 pa[2][ACH], pw[2][4];
     const int crow = tid >> 3, ckc = (tid & 7) * 8;           // chunk c = tid + 256*i -> row = crow + 32*i, k offset ckc
-    size_t aoff[4], woff[4];
+    size_t aoff[ACH], woff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int row = crow + 32 * i;
         // rows past M are clamped, not predicated: a branch per load makes the compiler serialise the loads behind
         // s_waitcnt at every join; the clamped rows only feed output rows the epilogue never stores
-        const int am = m0 + row < M ? m0 + row : M - 1;
-        aoff[i] = (size_t)am * lda + ckc;
+        if (i < ACH) {
+            const int am = m0 + row < M ? m0 + row : M - 1;
+            aoff[i] = (size_t)am * lda + ckc;
+        }
         woff[i] = (size_t)(n0 + row) * ldw + ckc;
     }
 #define GM3D_LOAD_STAGE(SET, K0)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-        pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));               \
+        if (i < ACH) pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));  \
         pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + (K0));               \
     }
 #define GM3D_STORE_STAGE(SET, ST)                                                         \
     {                                                                                     \
-        bf16_t* as_ = sm + (ST) * GSTAGE;                                                 \
-        bf16_t* ws_ = as_ + GBM * GPITCH;                                                 \
+        bf16_t* as_ = sm + (ST) * STAGE;                                                  \
+        bf16_t* ws_ = as_ + BM * GPITCH;                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                   \
             const int row = crow + 32 * i;                                                \
-            *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i];           \
+            if (i < ACH) *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i]; \
             *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];           \
         }                                                                                 \
     }
 
-    gf32x16 acc[2][2];
+    gf32x16 acc[WMI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -97,14 +105,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
 #define GM3D_ITER(KT_, CUR, NXT)                                                                                           \
     if ((KT_) < KT) {                                                                                                      \
         if ((KT_) + 2 < KT) GM3D_LOAD_STAGE(CUR, ((KT_) + 2) * GBK) /* stage KT_+2 reuses register set CUR */              \
-        const bf16_t* as = sm + (CUR) * GSTAGE;                                                                            \
-        const bf16_t* ws = as + GBM * GPITCH;                                                                              \
+        const bf16_t* as = sm + (CUR) * STAGE;                                                                             \
+        const bf16_t* ws = as + BM * GPITCH;                                                                               \
         /* all 16 operand fragments of the stage are requested from LDS before the first MFMA: one LDS round trip per */   \
         /* stage on the critical path instead of one per k-step (the compiler then drains lgkmcnt progressively)       */   \
-        gbf16x8 fa[4][2], fw[4][2];                                                                                        \
+        gbf16x8 fa[4][WMI], fw[4][2];                                                                                      \
         _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                    \
             const int ko = 16 * s + 8 * hh;                                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+            _Pragma("unroll") for (int i = 0; i < WMI; ++i)                                                                \
                 fa[s][i] = *reinterpret_cast<const gbf16x8*>(as + (wm + 32 * i + r) * GPITCH + ko);                        \
             _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                  \
                 fw[s][j] = *reinterpret_cast<const gbf16x8*>(ws + (wn + 32 * j + r) * GPITCH + ko);                        \
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
         __builtin_amdgcn_sched_barrier(0);   /* keep the scheduler from sinking the reads back between the MFMAs */        \
         /* transposed product: rows (registers) = n, columns (lanes) = m */                                                \
         _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                                      \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                  \
+            _Pragma("unroll") for (int i = 0; i < WMI; ++i)                                                                \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j], fa[s][i], acc[i][j], 0, 0, 0);           \
         if ((KT_) + 1 < KT) GM3D_STORE_STAGE(NXT, NXT)          /* stage KT_+1 (register set NXT) -> LDS buffer NXT */     \
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     // epilogue: acc -> fp32 tile in LDS (row = m, 4 consecutive n per register quad) -> + bias -> bf16, 16-byte stores
     float* cs = reinterpret_cast<float*>(gsm);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WMI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -146,8 +154,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
         const float b = bias ? bias[n0 + c] : 0.f;
         const float pre = bias_after_pool ? 0.f : b, post = bias_after_pool ? b : 0.f;
 #pragma unroll
-        for (int gi = 0; gi < 2; ++gi) {
-            const int rowbase = (gh * 2 + gi) * 32;
+        for (int gi = 0; gi < WMI; ++gi) {                       // BM/32 = 2*WMI groups per tile, WMI per thread-half
+            const int rowbase = (gh * WMI + gi) * 32;
             if (m0 + rowbase < M) {
                 float best = -INFINITY;
                 int bk = 0;
@@ -165,8 +173,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     }
     float csum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int c = tid + 256 * i;                 // 128 rows x 16 chunks of 8 columns
+    for (int i = 0; i < 4 * WMI; ++i) {
+        const int c = tid + 256 * i;                 // BM rows x 16 chunks of 8 columns
         const int row = c >> 4, nc = (c & 15) * 8;
         if (m0 + row < M) {
             float v[8];
@@ -248,6 +256,14 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 
 }  // namespace gm3d
 
+// 64-row tiles for the short token streams (3200 rows x N/128 column tiles is 75-300 workgroups for 512 slots), 128 otherwise;
+// GM3D_GEMM_BM=64|128 forces one (measurements)
+static int gemm_tile_height(int M) {
+    static const int forced = getenv("GM3D_GEMM_BM") ? atoi(getenv("GM3D_GEMM_BM")) : 0;
+    if (forced == 64 || forced == 128) return forced;
+    return M <= 4096 ? 64 : 128;
+}
+
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                        void* G, int ldg, gm3d_stream_t stream, void* P = nullptr, uint8_t* ARG = nullptr, int ldp = 0,
                        int bias_after_pool = 0, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr) {
@@ -257,40 +273,36 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
     if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
     if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int tiles_m = (M + GBM - 1) / GBM, tiles_n = N / GBN;
+    const int bm = gemm_tile_height(M);
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / GBN;
     if ((long long)tiles_m * tiles_n > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
-    const size_t lds_ab = (size_t)2 * GSTAGE * sizeof(bf16_t), lds_c = (size_t)GBM * GCP * sizeof(float);
+    const size_t lds_ab = (size_t)2 * (bm + GBN) * GPITCH * sizeof(bf16_t), lds_c = (size_t)bm * GCP * sizeof(float);
     const size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
-#define GM3D_GEMM_CASE(KTT)                                                                                                   \
-    case KTT: {                                                                                                               \
+#define GM3D_GEMM_LAUNCH(KTT, WMI)                                                                                             \
+    {                                                                                                                         \
         static bool attr_done = false;                                                                                        \
         if (!attr_done) {                                                                                                     \
-            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT, WMI>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                     (int)lds) != hipSuccess)                                                                  \
                 return GM3D_ELAUNCH;                                                                                          \
             attr_done = true;                                                                                                 \
         }                                                                                                                     \
-        hipLaunchKernelGGL(gemm_tn_bf16_kernel<KTT>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,       \
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<KTT, WMI>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
                            (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,      \
                            (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart);                        \
-        break;                                                                                                                \
     }
+#define GM3D_GEMM_CASE(KTT)                                                                                                   \
+    case KTT:                                                                                                                 \
+        if (bm == 64) GM3D_GEMM_LAUNCH(KTT, 1) else GM3D_GEMM_LAUNCH(KTT, 2)                                                  \
+        break;
     switch (K / GBK) {
         GM3D_GEMM_CASE(2) GM3D_GEMM_CASE(4) GM3D_GEMM_CASE(6) GM3D_GEMM_CASE(8) GM3D_GEMM_CASE(16) GM3D_GEMM_CASE(18)
         GM3D_GEMM_CASE(24)
-        default: {
-            static bool attr_done = false;
-            if (!attr_done) {
-                if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                    return GM3D_ELAUNCH;
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(gemm_tn_bf16_kernel<0>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,
-                               (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,
-                               (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart);
-        }
+        default:
+            if (bm == 64) GM3D_GEMM_LAUNCH(0, 1) else GM3D_GEMM_LAUNCH(0, 2)
     }
+#undef GM3D_GEMM_LAUNCH
 #undef GM3D_GEMM_CASE
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
@@ -320,7 +332,7 @@ extern "C" int gm3d_gemm_tn_bf16_gelu_bwd(const void* dO, const void* Wt, const 
     return gemm_launch(dO, Wt, bias, dF, M, N, K, lda, ldw, lddf, nullptr, 0, stream, nullptr, nullptr, 0, 0, F, ldf, colpart);
 }
 
-extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gm3d::GBM - 1) / gm3d::GBM; }
+extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gemm_tile_height(M) - 1) / gemm_tile_height(M); }
 
 extern "C" int gm3d_transpose_bf16_batched(const void* src, void* dst, int batch, int rows, int cols, long long src_batch_stride,
                                            gm3d_stream_t stream) {
