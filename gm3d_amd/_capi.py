@@ -63,6 +63,8 @@ SIGNATURES = {
     "gm3d_flat_partial_rows": [ctypes.c_longlong],
     "gm3d_adamw_ema_flat_step": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _f, _f, _f, _f,
                                  _vp, _f, _vp, _vp, _vp, _vp],
+    "gm3d_adamw_ema_flat_step_lrd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_longlong, _vp, _vp, _f, _f,
+                                     _f, _f, _vp, _f, _vp, _vp, _vp, _vp],
     "gm3d_group_scatter_add": [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "gm3d_pn_layer1_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_colsum_finish_f64": [_vp, _i, _i, _i, _vp, _vp],

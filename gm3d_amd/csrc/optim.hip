@@ -63,24 +63,26 @@ __global__ __launch_bounds__(256) void adamw_ema_flat_kernel(float* __restrict__
                                                              bf16_t* __restrict__ es, long long n, long long n_decay,
                                                              const float* __restrict__ lr_dev, float wd, float beta1,
                                                              float beta2, float eps, const float* __restrict__ ema_w_dev,
-                                                             const float* __restrict__ scal) {
+                                                             const float* __restrict__ scal,
+                                                             const float* __restrict__ lr_scale /*per element, or null*/) {
     const float lr = lr_dev[0], coef = scal[0], bc1 = scal[1], rbc2 = rsqrtf(scal[2]);
-    const float step_size = lr / bc1, ew = ema_w_dev ? ema_w_dev[0] : 0.f;
-    const float decay_mul = 1.0f - lr * wd;
+    const float ew = ema_w_dev ? ema_w_dev[0] : 0.f;
     const long long n4 = n >> 2;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         float4 P = reinterpret_cast<float4*>(p)[i];
         const float4 G = reinterpret_cast<const float4*>(g)[i];
         float4 M = reinterpret_cast<float4*>(m)[i], V = reinterpret_cast<float4*>(v)[i];
-        const float dm = (i * 4 < n_decay) ? decay_mul : 1.0f;   // n_decay % 4 == 0
+        float ls[4] = {1.f, 1.f, 1.f, 1.f};                      // layer-wise lr decay (fine-tuning): lr_eff = lr * lr_scale[i]
+        if (lr_scale) { const float4 S = reinterpret_cast<const float4*>(lr_scale)[i]; ls[0] = S.x; ls[1] = S.y; ls[2] = S.z; ls[3] = S.w; }
+        const bool decayed = i * 4 < n_decay;                    // n_decay % 4 == 0
         float pp[4] = {P.x, P.y, P.z, P.w}, gg[4] = {G.x, G.y, G.z, G.w}, mm[4] = {M.x, M.y, M.z, M.w}, vv[4] = {V.x, V.y, V.z, V.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const float gr = gg[k] * coef;
-            pp[k] *= dm;
+            const float gr = gg[k] * coef, lre = lr * ls[k];
+            pp[k] *= decayed ? 1.0f - lre * wd : 1.0f;
             mm[k] += (1.0f - beta1) * (gr - mm[k]);
             vv[k] = beta2 * vv[k] + (1.0f - beta2) * gr * gr;
-            pp[k] -= step_size * mm[k] / (sqrtf(vv[k]) * rbc2 + eps);
+            pp[k] -= (lre / bc1) * mm[k] / (sqrtf(vv[k]) * rbc2 + eps);
         }
         reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
         reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
@@ -103,11 +105,11 @@ static inline int flat_grid(long long n) { long long g = (n / 4 + 255) / 256; re
 
 extern "C" int gm3d_flat_partial_rows(long long n) { return n < 4 ? 0 : gm3d::flat_grid(n); }
 
-extern "C" int gm3d_adamw_ema_flat_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
-                                        void* shadow_p, void* shadow_e, long long n, long long n_decay,
-                                        const float* lr_dev, float weight_decay, float beta1, float beta2, float eps,
-                                        const float* ema_w_dev, float max_norm, float* step_dev, float* partial,
-                                        float* scal, gm3d_stream_t stream) {
+extern "C" int gm3d_adamw_ema_flat_step_lrd(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
+                                            void* shadow_p, void* shadow_e, long long n, long long n_decay,
+                                            const float* lr_dev, const float* lr_scale, float weight_decay, float beta1,
+                                            float beta2, float eps, const float* ema_w_dev, float max_norm, float* step_dev,
+                                            float* partial, float* scal, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!params || !grads || !exp_avg || !exp_avg_sq || !lr_dev || !step_dev || !partial || !scal || n < 4) return GM3D_EINVAL;
     if ((n & 3) || (n_decay & 3) || n_decay < 0 || n_decay > n) return GM3D_EINVAL;
@@ -119,7 +121,17 @@ extern "C" int gm3d_adamw_ema_flat_step(float* params, const float* grads, float
     hipLaunchKernelGGL(optim_prep_kernel, dim3(1), dim3(256), 0, st, partial, grid, max_norm, step_dev, beta1, beta2, scal);
     GM3D_CHECK_LAUNCH();
     hipLaunchKernelGGL(adamw_ema_flat_kernel, dim3(grid), dim3(256), 0, st, params, grads, exp_avg, exp_avg_sq, ema,
-                       (bf16_t*)shadow_p, (bf16_t*)shadow_e, n, n_decay, lr_dev, weight_decay, beta1, beta2, eps, ema_w_dev, scal);
+                       (bf16_t*)shadow_p, (bf16_t*)shadow_e, n, n_decay, lr_dev, weight_decay, beta1, beta2, eps, ema_w_dev, scal,
+                       lr_scale);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
+}
+
+extern "C" int gm3d_adamw_ema_flat_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, float* ema,
+                                        void* shadow_p, void* shadow_e, long long n, long long n_decay,
+                                        const float* lr_dev, float weight_decay, float beta1, float beta2, float eps,
+                                        const float* ema_w_dev, float max_norm, float* step_dev, float* partial,
+                                        float* scal, gm3d_stream_t stream) {
+    return gm3d_adamw_ema_flat_step_lrd(params, grads, exp_avg, exp_avg_sq, ema, shadow_p, shadow_e, n, n_decay, lr_dev, nullptr,
+                                        weight_decay, beta1, beta2, eps, ema_w_dev, max_norm, step_dev, partial, scal, stream);
 }

@@ -49,9 +49,19 @@ def param_groups_lrd(model, weight_decay=0.05, no_weight_decay_list=(), layer_de
     return list(groups.values())
 
 
-def build_optimizer(model, lr, weight_decay=0.05, layer_decay=0.75, capturable=False):
+def build_optimizer(model, lr, weight_decay=0.05, layer_decay=0.75, capturable=False, flat=False, max_norm=None,
+                    num_layers=12):
     """torch.optim.AdamW(param_groups_lrd(...), lr) as in P/main_finetune.py:359-365 (multi-tensor fused update).
-    capturable=True: per-group learning rates live in device tensors (hipGraph capture)."""
+    capturable=True: per-group learning rates live in device tensors (hipGraph capture).
+    flat=True: the same update (same groups: lr_scale per layer, no weight decay for 1-D parameters) as ONE pass over flat
+    buffers -- optim.FlatAdamWEma with a per-element lr multiplier; gradient clipping (`max_norm`) happens inside its
+    step, the learning rate is a device scalar (graph-capturable), and the GEMMs read the bf16 shadows it maintains."""
+    if flat:
+        from .optim import FlatAdamWEma
+        scales = [layer_decay ** (num_layers - i) for i in range(num_layers + 1)]
+        return FlatAdamWEma(model, None, lr=lr, weight_decay=weight_decay, max_norm=max_norm if max_norm else 0.0,
+                            no_decay_of=lambda n, p: p.ndim == 1,
+                            lr_scale_of=lambda n: scales[get_layer_id_for_vit(n, num_layers)])
     groups = [{k: v for k, v in g.items() if k != "names"} for g in param_groups_lrd(
         model, weight_decay, no_weight_decay_list=[{"pos_embed", "cls_token"}], layer_decay=layer_decay)]
     dev = next(model.parameters()).device
@@ -107,7 +117,10 @@ def finetune_step(model, criterion, optimizer, points, targets, npoints=1024, ma
         loss = criterion(outputs.float(), targets.long())
     (loss / accum_iter).backward()
     gnorm = None
-    if update:
+    if update and hasattr(optimizer, "flat_grad_views"):      # FlatAdamWEma: clip + AdamW in one pass (its own max_norm)
+        gnorm = optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    elif update:
         params = [p for p in model.parameters() if p.grad is not None]
         if max_norm is not None:
             gnorm = torch.nn.utils.clip_grad_norm_(params, max_norm, foreach=True)
@@ -187,7 +200,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, los
             seen += 1
             if log_writer is not None:
                 log_writer.add_scalar("loss", v, int((it / n_iter + epoch) * 1000))
-    lrs = [g["lr"] for g in optimizer.param_groups]
+    lrs = [float(g["lr"]) for g in optimizer.param_groups]
     return {"loss": loss_sum / max(seen, 1), "lr": max(lrs)}
 
 

@@ -15,12 +15,18 @@ from ._capi import check, lib
 from .ops import _ptr, _stream
 
 
-def _split_decay(model, segment_of=None):
+def _builder_no_decay(name, p):
+    """P/tools/builder.py:40-56."""
+    return len(p.shape) == 1 or name.endswith(".bias") or "token" in name
+
+
+def _split_decay(model, segment_of=None, no_decay_of=None):
+    no_decay_of = no_decay_of or _builder_no_decay
     decay, no_decay = [], []
     for name, p in model.named_parameters():
         if not p.requires_grad:
             continue
-        (no_decay if (len(p.shape) == 1 or name.endswith(".bias") or "token" in name) else decay).append((name, p))
+        (no_decay if no_decay_of(name, p) else decay).append((name, p))
     if segment_of is not None:      # stable: parameters keep their order inside a segment
         decay.sort(key=lambda kv: segment_of(kv[0]))
         no_decay.sort(key=lambda kv: segment_of(kv[0]))
@@ -29,12 +35,15 @@ def _split_decay(model, segment_of=None):
 
 class FlatAdamWEma(torch.optim.Optimizer):
     def __init__(self, model, model_ema=None, lr=1e-3, weight_decay=0.05, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0,
-                 segment_of=None):
-        """segment_of(name) -> int (optional): lay the decayed parameters out segment by segment (ascending), so that the
+                 segment_of=None, no_decay_of=None, lr_scale_of=None):
+        """no_decay_of(name, p) -> bool (optional) replaces the pretraining rule for which parameters skip weight decay;
+        lr_scale_of(name) -> float (optional) gives every parameter a learning-rate multiplier (fine-tuning's layer-wise lr
+        decay, P/util/lr_decay.py): the step then reads a per-element multiplier buffer laid out like the parameters.
+        segment_of(name) -> int (optional): lay the decayed parameters out segment by segment (ascending), so that the
         gradients of one backward segment form ONE contiguous range of the flat buffer (`segment_ranges`: data-parallel runs
         all-reduce a segment's range while the next segment's backward is still running).  All non-decayed parameters (biases,
         LayerNorm / BatchNorm affine, tokens: <1 % of the bytes) follow the last segment and travel with it."""
-        decay, no_decay = _split_decay(model, segment_of)
+        decay, no_decay = _split_decay(model, segment_of, no_decay_of)
         named = decay + no_decay
         params = [p for _, p in named]
         dev = params[0].device
@@ -78,6 +87,11 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 self.ES.copy_(self.E)
             model_ema.params_in_optimizer = True
             model_ema._pairs = None
+        self.LS = None
+        if lr_scale_of is not None:
+            self.LS = torch.ones(self.n, **f32)
+            for (name, p), o in zip(named, offs):
+                self.LS[o:o + p.numel()] = float(lr_scale_of(name))
         self.lr_dev = torch.tensor(float(lr), **f32)
         self.step_dev = torch.zeros(1, **f32)
         self.ema_w_dev = torch.zeros(1, **f32)
@@ -176,9 +190,9 @@ class FlatAdamWEma(torch.optim.Optimizer):
         g = self.param_groups[0]
         if self.ema is not None:
             self.ema_w_dev.fill_(1.0 - float(self.ema.decay))
-        check(lib.gm3d_adamw_ema_flat_step(_ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS),
-                                           _ptr(self.ES), self.n, self.n_decay, _ptr(self.lr_dev), float(g["weight_decay"]),
-                                           float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), _ptr(self.ema_w_dev),
-                                           self.max_norm, _ptr(self.step_dev), _ptr(self.partial), _ptr(self.scal), _stream()),
-              "gm3d_adamw_ema_flat_step")
+        check(lib.gm3d_adamw_ema_flat_step_lrd(
+            _ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS), _ptr(self.ES), self.n,
+            self.n_decay, _ptr(self.lr_dev), _ptr(self.LS), float(g["weight_decay"]), float(g["betas"][0]),
+            float(g["betas"][1]), float(g["eps"]), _ptr(self.ema_w_dev), self.max_norm, _ptr(self.step_dev),
+            _ptr(self.partial), _ptr(self.scal), _stream()), "gm3d_adamw_ema_flat_step_lrd")
         return self.scal[3]

@@ -233,6 +233,13 @@ int gm3d_adamw_ema_flat_step(float *params, const float *grads, float *exp_avg, 
                              void *shadow_p, void *shadow_e, long long n, long long n_decay, const float *lr_dev,
                              float weight_decay, float beta1, float beta2, float eps, const float *ema_w_dev,
                              float max_norm, float *step_dev, float *partial, float *scal, gm3d_stream_t stream);
+/* The same step with layer-wise learning-rate decay (fine-tuning: Point-MAE_SA3D/util/lr_decay.py:15-62 builds one AdamW
+ * group per layer with lr = base_lr * lr_scale): lr_scale holds one multiplier per element, in the flat layout (NULL = 1). */
+int gm3d_adamw_ema_flat_step_lrd(float *params, const float *grads, float *exp_avg, float *exp_avg_sq, float *ema,
+                                 void *shadow_p, void *shadow_e, long long n, long long n_decay, const float *lr_dev,
+                                 const float *lr_scale, float weight_decay, float beta1, float beta2, float eps,
+                                 const float *ema_w_dev, float max_norm, float *step_dev, float *partial, float *scal,
+                                 gm3d_stream_t stream);
 
 /* BatchNorm statistic finalisation in one launch (train: from sums = [sum(C), sumsq(C)] over `rows` rows, with
  * nn.BatchNorm1d's running-statistic update -- momentum, unbiased variance, num_batches_tracked += 1; eval: from the
