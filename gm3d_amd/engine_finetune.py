@@ -106,10 +106,11 @@ def sample_points(points, npoints, subset=None, rng=np.random):
 
 
 def finetune_step(model, criterion, optimizer, points, targets, npoints=1024, max_norm=None, bf16=True, subset=None,
-                  aug_draws=None, augment=True, update=True, accum_iter=1):
+                  aug_draws=None, augment=True, update=True, accum_iter=1, presampled=False):
     """One iteration of P/engine_finetune.py:108-151.  points (B,N0,3) f32 and targets (B,) on the GPU.
+    presampled=True: `points` already is the (B,npoints,3) output of sample_points (sampling overlapped elsewhere).
     -> {'loss', 'grad_norm', 'outputs'} as device tensors (no host sync)."""
-    pts = sample_points(points, npoints, subset=subset)
+    pts = points if presampled else sample_points(points, npoints, subset=subset)
     if augment:
         pts = train_transforms(pts, draws=aug_draws)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
@@ -133,11 +134,16 @@ class GraphedFinetuneStep:
     """The fine-tune iteration captured once as a hipGraph and replayed: at the reference's batch sizes (32-40 clouds) the
     step is a few hundred short launches and the host cannot keep the GPU fed.  Static inputs: the raw clouds, the
     labels and the random FPS subset (drawn on the host per call, copied in); the augmentation and DropPath/Dropout draws
-    use the graph-safe device generator.  Needs an optimizer built with capturable=True (build_optimizer(...,
-    capturable=True)): its learning rates are device tensors that adjust_learning_rate fills in place."""
+    use the graph-safe device generator.  Needs an optimizer whose learning rates are device tensors that
+    adjust_learning_rate fills in place: build_optimizer(..., capturable=True) or build_optimizer(..., flat=True).
+
+    overlap_sampling=True: the point sampling (FPS 8192 -> point_all: one workgroup per cloud, 32-40 of the 256 CUs busy for
+    >1 ms, a quarter of the step) is captured as its OWN graph and replayed on a second stream for the NEXT batch while the
+    training graph of the current batch runs: call step(points, targets, next_points=<the following batch>).  Same
+    arithmetic and the same order of host random draws as the single-graph form."""
 
     def __init__(self, model, criterion, optimizer, example_points, example_targets, npoints=1024, max_norm=None, bf16=True,
-                 warmup_iters=3, rng=np.random, augment=True):
+                 warmup_iters=3, rng=np.random, augment=True, overlap_sampling=False):
         """The `warmup_iters` un-captured iterations are real optimisation steps on the example batch (the allocator and
         the optimizer state must be warm before capture): pass warmup_iters=0 when the optimizer state already exists."""
         self.model, self.criterion, self.opt = model, criterion, optimizer
@@ -146,7 +152,17 @@ class GraphedFinetuneStep:
         self.points = example_points.clone()
         self.targets = example_targets.clone()
         self.subset = torch.zeros(npoints, dtype=torch.long, device=example_points.device)
+        self._pin = [torch.empty(npoints, dtype=torch.long).pin_memory() for _ in range(2)]
+        self._pin_ev, self._pin_i = [None, None], 0
+        self.overlap = bool(overlap_sampling)
         self._draw()
+        if self.overlap:
+            B = example_points.size(0)
+            self.staged = torch.zeros(B, npoints, 3, dtype=torch.float32, device=example_points.device)
+            self.pts = torch.zeros_like(self.staged)
+            self.pts.copy_(sample_points(self.points, npoints, subset=self.subset))
+            self.sstream = torch.cuda.Stream()
+            self._ready, self._staged = torch.cuda.Event(), False
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -157,39 +173,101 @@ class GraphedFinetuneStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._body()
+        if self.overlap:
+            self.sample_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.sample_graph, stream=self.sstream):
+                self.staged.copy_(sample_points(self.points, npoints, subset=self.subset))
+            torch.cuda.synchronize()
 
     def _draw(self):
-        self.subset.copy_(torch.from_numpy(self.rng.choice(self.point_all, self.npoints, False).astype(np.int64)))
+        """Host draw of the shared FPS subset -> device, through two alternating pinned buffers so that the copy is
+        asynchronous (a pageable copy would make the host wait for everything queued before it, once per step)."""
+        i, self._pin_i = self._pin_i, self._pin_i ^ 1
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        self._pin[i].copy_(torch.from_numpy(self.rng.choice(self.point_all, self.npoints, False).astype(np.int64)))
+        self.subset.copy_(self._pin[i], non_blocking=True)
+        self._pin_ev[i] = torch.cuda.Event()
+        self._pin_ev[i].record(torch.cuda.current_stream())
 
     def _body(self):
+        if self.overlap:
+            return finetune_step(self.model, self.criterion, self.opt, self.pts, self.targets, npoints=self.npoints,
+                                 max_norm=self.max_norm, bf16=self.bf16, augment=self.augment, presampled=True)
         return finetune_step(self.model, self.criterion, self.opt, self.points, self.targets, npoints=self.npoints,
                              max_norm=self.max_norm, bf16=self.bf16, subset=self.subset, augment=self.augment)
 
-    def __call__(self, points, targets):
-        self.points.copy_(points, non_blocking=True)
+    def _enqueue_sampling(self, points):
+        """Sampler stream: (after everything the caller's stream has queued so far -- the producer of `points`, and the copy that
+        consumed the previous staged batch) clouds in, subset draw, FPS + gather graph -> self.staged."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        with torch.cuda.stream(self.sstream):
+            self.sstream.wait_event(ev)
+            self.points.copy_(points, non_blocking=True)
+            points.record_stream(self.sstream)
+            self._draw()
+            self.sample_graph.replay()
+            self._ready.record(self.sstream)
+        self._staged = True
+
+    def __call__(self, points, targets, next_points=None):
+        if not self.overlap:
+            self.points.copy_(points, non_blocking=True)
+            self.targets.copy_(targets, non_blocking=True)
+            self._draw()
+            self.graph.replay()
+            return self.out
+        main = torch.cuda.current_stream()
+        if not self._staged:                      # first call (or no look-ahead given last time): sample this batch now
+            self._enqueue_sampling(points)
+        main.wait_event(self._ready)
+        self.pts.copy_(self.staged)
         self.targets.copy_(targets, non_blocking=True)
-        self._draw()
+        self._staged = False
+        if next_points is not None:               # queued BEFORE the training graph so that the two run side by side
+            self._enqueue_sampling(next_points)
         self.graph.replay()
         return self.out
 
 
 def train_one_epoch(model, criterion, data_loader, optimizer, device, epoch, loss_scaler=None, max_norm=0,
-                    mixup_fn=None, log_writer=None, args=None, npoints=0, print_freq=20):
+                    mixup_fn=None, log_writer=None, args=None, npoints=0, print_freq=20, step=None):
     """Reference signature (P/engine_finetune.py:70-74).  The loss is read on the host every `print_freq` iterations
-    (the reference syncs on loss.item() every iteration; a non-finite loss still stops the run at the next read)."""
+    (the reference syncs on loss.item() every iteration; a non-finite loss still stops the run at the next read).
+    step: a GraphedFinetuneStep built on this model / optimizer -- the iteration is then a graph replay, and with
+    overlap_sampling the loader is read one batch ahead so that the next batch's point sampling runs beside the current
+    batch's training graph (accum_iter must be 1; a last batch of a different size runs eagerly)."""
     model.train(True)
     accum_iter = getattr(args, "accum_iter", 1)
+    if step is not None and accum_iter != 1:
+        raise NotImplementedError("graph replay with gradient accumulation")
     optimizer.zero_grad(set_to_none=True)
     n_iter = len(data_loader)
     seen, loss_sum, last = 0, 0.0, None
-    for it, (_taxonomy_ids, _model_ids, data) in enumerate(data_loader):
+
+    def batches():          # (it, points, targets, next batch's points or None), everything already on the device
+        prev = None
+        for it, (_taxonomy_ids, _model_ids, data) in enumerate(data_loader):
+            cur = (it, data[0].to(device, non_blocking=True), data[1].to(device, non_blocking=True))
+            if prev is not None:
+                yield prev + (cur[1],)
+            prev = cur
+        if prev is not None:
+            yield prev + (None,)
+
+    for it, points, targets, nxt in batches():
         if it % accum_iter == 0:
             adjust_learning_rate(optimizer, it / n_iter + epoch, args)
-        points = data[0].to(device, non_blocking=True)
-        targets = data[1].to(device, non_blocking=True)
-        out = finetune_step(model, criterion, optimizer, points, targets, npoints=npoints,
-                            max_norm=max_norm if max_norm else None, bf16=getattr(args, "bf16", True),
-                            update=(it + 1) % accum_iter == 0, accum_iter=accum_iter)
+        if step is not None and points.shape == step.points.shape:
+            if step.overlap:
+                out = step(points, targets, next_points=nxt if nxt is not None and nxt.shape == points.shape else None)
+            else:
+                out = step(points, targets)
+        else:
+            out = finetune_step(model, criterion, optimizer, points, targets, npoints=npoints,
+                                max_norm=max_norm if max_norm else None, bf16=getattr(args, "bf16", True),
+                                update=(it + 1) % accum_iter == 0, accum_iter=accum_iter)
         last = out["loss"]
         if (it + 1) % print_freq == 0 or it + 1 == n_iter:
             v = float(last)

@@ -49,6 +49,22 @@ def test_finetune_train_one_epoch_and_evaluate():
                                args=args, npoints=1024, print_freq=1)
     assert stats["loss"] == stats["loss"] and stats["lr"] > 0
     assert not torch.equal(model.cls_head_finetune[0].weight, before)
+    # the same epoch as graph replays with the flat layer-decay optimizer and the sampling of batch i+1 overlapped with batch i;
+    # the loader ends on a smaller batch, which runs eagerly
+    model2 = PointTransformer(dict(trans_dim=384, depth=12, drop_path_rate=0.1, cls_dim=40, num_heads=6, group_size=32, num_group=64,
+                                   encoder_dims=384)).cuda()
+    opt2 = EF.build_optimizer(model2, lr=5e-4, flat=True, max_norm=10.0)
+    EF.adjust_learning_rate(opt2, 20.0, args)
+    ex = clouds.gaussian(8, 2048, seed=10).cuda()
+    g = EF.GraphedFinetuneStep(model2, nn.CrossEntropyLoss(), opt2, ex, (torch.arange(8) % 40).cuda(), npoints=1024, max_norm=10.0,
+                               overlap_sampling=True)
+    items = [(None, None, (clouds.gaussian(8, 2048, seed=10 + i), torch.arange(8) % 40)) for i in range(3)]
+    items.append((None, None, (clouds.gaussian(5, 2048, seed=19), torch.arange(5) % 40)))
+    before2 = model2.cls_head_finetune[0].weight.detach().clone()
+    stats2 = EF.train_one_epoch(model2, nn.CrossEntropyLoss(), Loader(iter(items)), opt2, torch.device("cuda"), 20, None, 10.0, None,
+                                log_writer=None, args=args, npoints=1024, print_freq=1, step=g)
+    assert stats2["loss"] == stats2["loss"] and stats2["lr"] > 0
+    assert not torch.equal(model2.cls_head_finetune[0].weight, before2)
     ev = EF.evaluate([(None, None, (clouds.gaussian(4, 2048, seed=3), torch.arange(4).view(4, 1)))], model, "cuda", npoints=1024)
     assert ev["n"] == 4 and 0.0 <= ev["acc1"] <= 100.0
 

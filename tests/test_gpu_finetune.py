@@ -225,7 +225,7 @@ def test_graph_replay_equals_eager(M):
     targets = (torch.arange(8).cuda() * 3) % 40
     args = SimpleNamespace(lr=1e-3, min_lr=1e-6, warmup_epochs=0, epochs=300)
 
-    def run(graphed, flat=False):
+    def run(graphed, flat=False, overlap=False):
         pm = build(seed=9, drop_path=0.0)
         pm.train()
         opt = EF.build_optimizer(pm, lr=1e-3, capturable=True, flat=flat, max_norm=10.0)
@@ -235,8 +235,9 @@ def test_graph_replay_equals_eager(M):
         if graphed:
             # warm-up iterations are real steps: give the eager side the same three
             g = EF.GraphedFinetuneStep(pm, crit, opt, batches[0], targets, npoints=1024, max_norm=10.0, bf16=False, rng=rng,
-                                       augment=False, warmup_iters=3)
-            step = lambda x: g(x, targets)
+                                       augment=False, warmup_iters=3, overlap_sampling=overlap)
+            nxt = {id(a): b for a, b in zip(batches, batches[1:])}
+            step = (lambda x: g(x, targets, next_points=nxt.get(id(x)))) if overlap else (lambda x: g(x, targets))
         else:
             sub = rng.choice(1200, 1024, False)
             for _ in range(3):          # the 3 warm-up iterations (capture itself executes nothing), on batches[0] with the first subset
@@ -260,3 +261,7 @@ def test_graph_replay_equals_eager(M):
     assert max(abs(a - b) for a, b in zip(lfe, lf)) <= 1e-5 * max(lfe)
     assert max(rel(pf[k], pfe[k]) for k in pfe) <= 1e-5
     assert max(abs(a - b) for a, b in zip(le, lf)) <= 5e-3 * max(le)
+    # the sampling graph of batch i+1 replayed on a second stream beside the training graph of batch i: same numbers
+    lo, po = run(True, flat=True, overlap=True)
+    assert max(abs(a - b) for a, b in zip(lf, lo)) <= 1e-6 * max(lf)
+    assert max(rel(po[k], pf[k]) for k in pf) <= 1e-6

@@ -106,5 +106,14 @@ try:
     res["graph_flat_clouds_per_s"], res["graph_flat_ms"] = timed(graphed_flat)
 except Exception as ex:
     res["graph_flat_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:200])
+try:
+    go = EF.GraphedFinetuneStep(model, crit, fopt, pool[0], targets, npoints=1024, max_norm=10.0, bf16=not a.fp32, warmup_iters=0,
+                                overlap_sampling=True)
+    def graphed_overlap(i):
+        EF.adjust_learning_rate(fopt, 20 + i / 100.0, args)
+        return go(pool[i % 3], targets, next_points=pool[(i + 1) % 3])
+    res["graph_flat_overlap_clouds_per_s"], res["graph_flat_overlap_ms"] = timed(graphed_overlap)
+except Exception as ex:
+    res["graph_flat_overlap_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:200])
 res.update(metric="point-clouds/sec fine-tune step (8192->1024 pts, G=64, cls 40)", batch=a.batch, dtype="f32" if a.fp32 else "bf16")
 print(json.dumps(res))
