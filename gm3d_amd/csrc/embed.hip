@@ -176,22 +176,22 @@ __global__ __launch_bounds__(256) void bn_bcast_stats_kernel(const T* __restrict
 template <class T>
 __global__ __launch_bounds__(256) void bn_bcast_apply_relu_kernel(const T* __restrict__ y0, const T* __restrict__ t, const float* __restrict__ scale,
                                            const float* __restrict__ shift, T* __restrict__ a2, int G, int K, int C,
-                                           float slope) {
+                                           float slope, const int* __restrict__ sel /*source group of output group g, or null*/) {
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
     float sc[8], sh[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; }
     for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        const int sg = sel ? sel[g] : g;
         float tv[8];
-        V8<T>::load(t + (size_t)g * C + c, tv);
+        V8<T>::load(t + (size_t)sg * C + c, tv);
         for (int k = sl; k < K; k += SL) {
             float v[8];
-            const size_t o = ((size_t)g * K + k) * C + c;
-            V8<T>::load(y0 + o, v);
+            V8<T>::load(y0 + ((size_t)sg * K + k) * C + c, v);
 #pragma unroll
             for (int i = 0; i < 8; ++i) { const float h = (v[i] + tv[i]) * sc[i] + sh[i]; v[i] = h > 0.f ? h : slope * h; }
-            V8<T>::store(a2 + o, v);
+            V8<T>::store(a2 + ((size_t)g * K + k) * C + c, v);
         }
     }
 }
@@ -202,7 +202,8 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bcast_bwd_stats_kernel(const T* __restrict__ da2, const T* __restrict__ y0, const T* __restrict__ t,
                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                           const float* __restrict__ mean, const float* __restrict__ rstd, int G, int K, int C,
-                                          float* __restrict__ partial, float slope) {
+                                          float* __restrict__ partial, float slope,
+                                          const int* __restrict__ sel /*da2 holds G selected groups; y0/t group of da2 group g, or null*/) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
@@ -210,13 +211,13 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_stats_kernel(const T* __rest
 #pragma unroll
     for (int i = 0; i < 8; ++i) { sc[i] = scale[c + i]; sh[i] = shift[c + i]; mu[i] = mean[c + i]; rs[i] = rstd[c + i]; acc[0][i] = acc[1][i] = 0.f; }
     for (int g = blockIdx.x; g < G; g += gridDim.x) {
+        const int sg = sel ? sel[g] : g;
         float tv[8];
-        V8<T>::load(t + (size_t)g * C + c, tv);
+        V8<T>::load(t + (size_t)sg * C + c, tv);
         for (int k = sl; k < K; k += SL) {
             float v[8], d[8];
-            const size_t o = ((size_t)g * K + k) * C + c;
-            V8<T>::load(y0 + o, v);
-            V8<T>::load(da2 + o, d);
+            V8<T>::load(y0 + ((size_t)sg * K + k) * C + c, v);
+            V8<T>::load(da2 + ((size_t)g * K + k) * C + c, d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float y = v[i] + tv[i];
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __rest
                                                                  const float* __restrict__ rstd, const float* __restrict__ s1,
                                                                  const float* __restrict__ s2, float inv_rows,
                                                                  T* __restrict__ dy, float* __restrict__ dt, int G, int K, int C,
-                                                                 float slope) {
+                                                                 float slope,
+                                                                 const int* __restrict__ inv /*group -> its group in da2, -1: da2 = 0; or null*/) {
     const int tpr = C >> 3, gpb = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, gl = threadIdx.x / tpr, c = lane * 8;
     float sc[8], sh[8], mu[8], rs[8], m1[8], m2[8];
@@ -248,6 +250,7 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __rest
         m1[i] = s1[c + i] * inv_rows; m2[i] = s2[c + i] * inv_rows;
     }
     for (int g = blockIdx.x * gpb + gl; g < G; g += gridDim.x * gpb) {
+        const int cg = inv ? inv[g] : g;
         float tv[8], gs[8];
         V8<T>::load(t + (size_t)g * C + c, tv);
 #pragma unroll
@@ -257,8 +260,12 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __rest
             float v[4][8], d[4][8];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const size_t o = ((size_t)g * K + k + u) * C + c;
-                V8<T>::load(y0 + o, v[u]); V8<T>::load(da2 + o, d[u]);
+                V8<T>::load(y0 + ((size_t)g * K + k + u) * C + c, v[u]);
+                if (cg >= 0) V8<T>::load(da2 + ((size_t)cg * K + k + u) * C + c, d[u]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) d[u][i] = 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -273,9 +280,10 @@ __global__ __launch_bounds__(256) void bn_bcast_bwd_apply_kernel(const T* __rest
             }
         }
         for (; k < K; ++k) {
-            float v[8], d[8];
+            float v[8], d[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const size_t o = ((size_t)g * K + k) * C + c;
-            V8<T>::load(y0 + o, v); V8<T>::load(da2 + o, d);
+            V8<T>::load(y0 + o, v);
+            if (cg >= 0) V8<T>::load(da2 + ((size_t)cg * K + k) * C + c, d);
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float y = v[i] + tv[i];
@@ -647,6 +655,21 @@ __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict
 // for all j -- the boolean-mask gathers and the concat of P/models_mae_learn_loss.py:298-300,649-658 in one pass.
 // Backward: because `order` is a permutation every source row is written exactly once (no atomics, no zero fill):
 // dtokens[b,order[b,j]] = j < V ? dx_vis[b,j] : 0 ; dpos[b,order[b,j]] = dpos_full[b,j] + (j < V ? dpos_vis[b,j] : 0).
+// ids (B, V) int64 with row pitch `pitch` (the visible ids of every cloud) -> sel[b*V + v] = b*G + ids[b][v] (selected group list)
+// and inv[b*G + g] = position of group g in that list, -1 when it is not selected.  One workgroup per cloud.
+__global__ __launch_bounds__(256) void group_select_maps_kernel(const long long* __restrict__ ids, int pitch, int V, int G,
+                                                                int* __restrict__ sel, int* __restrict__ inv) {
+    const int b = blockIdx.x;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) inv[(size_t)b * G + g] = -1;
+    __syncthreads();
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+        long long g = ids[(size_t)b * pitch + v];
+        g = g < 0 ? 0 : (g >= G ? G - 1 : g);                 // ids are produced on the device: keep every later access in bounds
+        sel[(size_t)b * V + v] = b * G + (int)g;
+        inv[(size_t)b * G + g] = b * V + v;
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(64) void token_assemble_fwd_kernel(const T* __restrict__ tokens, const T* __restrict__ pos,
                                                                 const long long* __restrict__ order, int L, int V, int C,
@@ -661,9 +684,11 @@ __global__ __launch_bounds__(64) void token_assemble_fwd_kernel(const T* __restr
         V8<T>::store(pos_full + dfull + c, p);
         if (j < V) {
             V8<T>::store(pos_vis + dvis + c, p);
-            float t[8];
-            V8<T>::load(tokens + src + c, t);
-            V8<T>::store(x_vis + dvis + c, t);
+            if (tokens) {
+                float t[8];
+                V8<T>::load(tokens + src + c, t);
+                V8<T>::store(x_vis + dvis + c, t);
+            }
         }
     }
 }
@@ -688,7 +713,7 @@ __global__ __launch_bounds__(64) void token_assemble_bwd_kernel(const T* __restr
             if (dx_vis) V8<T>::load(dx_vis + svis + c, t);
         }
         V8<T>::store(dpos + dst + c, g);
-        V8<T>::store(dtokens + dst + c, t);
+        if (dtokens) V8<T>::store(dtokens + dst + c, t);
     }
 }
 
@@ -794,8 +819,8 @@ extern "C" int gm3d_bn_bcast_stats(const void* y0, const void* t, int G, int K, 
     return GM3D_OK;
 }
 
-extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const float* scale, const float* shift, void* a2,
-                                        int G, int K, int C, float slope, int dtype, gm3d_stream_t stream) {
+extern "C" int gm3d_bn_bcast_apply_relu_sel(const void* y0, const void* t, const float* scale, const float* shift, void* a2,
+                                            const int* sel, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
@@ -803,16 +828,21 @@ extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const flo
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
-                                     (const bf16_t*)y0, (const bf16_t*)t, scale, shift, (bf16_t*)a2, G, K, C, slope),
+                                     (const bf16_t*)y0, (const bf16_t*)t, scale, shift, (bf16_t*)a2, G, K, C, slope, sel),
                   hipLaunchKernelGGL(bn_bcast_apply_relu_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), 0, st,
-                                     (const float*)y0, (const float*)t, scale, shift, (float*)a2, G, K, C, slope));
+                                     (const float*)y0, (const float*)t, scale, shift, (float*)a2, G, K, C, slope, sel));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
 
-extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const void* t, const float* scale,
-                                       const float* shift, const float* mean, const float* rstd, int G, int K, int C,
-                                       float* partial, float slope, int dtype, gm3d_stream_t stream) {
+extern "C" int gm3d_bn_bcast_apply_relu(const void* y0, const void* t, const float* scale, const float* shift, void* a2,
+                                        int G, int K, int C, float slope, int dtype, gm3d_stream_t stream) {
+    return gm3d_bn_bcast_apply_relu_sel(y0, t, scale, shift, a2, nullptr, G, K, C, slope, dtype, stream);
+}
+
+extern "C" int gm3d_bn_bcast_bwd_stats_sel(const void* da2, const void* y0, const void* t, const float* scale,
+                                           const float* shift, const float* mean, const float* rstd, const int* sel, int G, int K,
+                                           int C, float* partial, float slope, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
@@ -821,17 +851,23 @@ extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const vo
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<bf16_t>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
-                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, G, K, C, partial, slope),
+                                     (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, G, K, C, partial, slope, sel),
                   hipLaunchKernelGGL(bn_bcast_bwd_stats_kernel<float>, dim3(group_grid(G)), dim3(threads_for(C)), lds, st,
-                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, G, K, C, partial, slope));
+                                     (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, G, K, C, partial, slope, sel));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
 
-extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const void* t, const float* scale,
-                                       const float* shift, const float* mean, const float* rstd, const float* s1,
-                                       const float* s2, void* dy, float* dt, int G, int K, int C, float slope, int dtype,
-                                       gm3d_stream_t stream) {
+extern "C" int gm3d_bn_bcast_bwd_stats(const void* da2, const void* y0, const void* t, const float* scale,
+                                       const float* shift, const float* mean, const float* rstd, int G, int K, int C,
+                                       float* partial, float slope, int dtype, gm3d_stream_t stream) {
+    return gm3d_bn_bcast_bwd_stats_sel(da2, y0, t, scale, shift, mean, rstd, nullptr, G, K, C, partial, slope, dtype, stream);
+}
+
+extern "C" int gm3d_bn_bcast_bwd_apply_sel(const void* da2, const void* y0, const void* t, const float* scale,
+                                           const float* shift, const float* mean, const float* rstd, const float* s1,
+                                           const float* s2, void* dy, float* dt, const int* inv, int G, int K, int C, float slope,
+                                           int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     int rc = gkc_check(y0, t, G, K, C, dtype);
     if (rc != GM3D_OK) return rc;
@@ -843,10 +879,28 @@ extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const vo
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const bf16_t*)da2, (const bf16_t*)y0, (const bf16_t*)t, scale, shift, mean, rstd, s1, s2,
-                                     inv_rows, (bf16_t*)dy, dt, G, K, C, slope),
+                                     inv_rows, (bf16_t*)dy, dt, G, K, C, slope, inv),
                   hipLaunchKernelGGL(bn_bcast_bwd_apply_kernel<float>, dim3(grid), dim3(gpb * (C / 8)), 0, st,
                                      (const float*)da2, (const float*)y0, (const float*)t, scale, shift, mean, rstd, s1, s2,
-                                     inv_rows, (float*)dy, dt, G, K, C, slope));
+                                     inv_rows, (float*)dy, dt, G, K, C, slope, inv));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const void* t, const float* scale,
+                                       const float* shift, const float* mean, const float* rstd, const float* s1,
+                                       const float* s2, void* dy, float* dt, int G, int K, int C, float slope, int dtype,
+                                       gm3d_stream_t stream) {
+    return gm3d_bn_bcast_bwd_apply_sel(da2, y0, t, scale, shift, mean, rstd, s1, s2, dy, dt, nullptr, G, K, C, slope, dtype, stream);
+}
+
+extern "C" int gm3d_group_select_maps(const long long* ids, int id_pitch, int B, int V, int G, int* sel, int* inv,
+                                      gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!ids || !sel || !inv || B < 0 || V < 0 || G < 1 || V > G || id_pitch < V) return GM3D_EINVAL;
+    if ((long long)B * G > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
+    if (B == 0) return GM3D_OK;
+    hipLaunchKernelGGL(group_select_maps_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, ids, id_pitch, V, G, sel, inv);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -1009,7 +1063,8 @@ extern "C" int gm3d_mask_select(const float* loss_pred, const float* noise, int 
 extern "C" int gm3d_token_assemble_fwd(const void* tokens, const void* pos, const long long* order, int B, int L, int V, int C,
                                        void* x_vis, void* pos_vis, void* pos_full, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!tokens || !pos || !order || !x_vis || !pos_vis || !pos_full || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;
+    if (!pos || !order || !pos_vis || !pos_full || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;
+    if ((tokens == nullptr) != (x_vis == nullptr)) return GM3D_EINVAL;      // both NULL: positions only (tokens already visible-only)
     if (C % 8) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;
@@ -1026,7 +1081,7 @@ extern "C" int gm3d_token_assemble_fwd(const void* tokens, const void* pos, cons
 extern "C" int gm3d_token_assemble_bwd(const void* dx_vis, const void* dpos_vis, const void* dpos_full, const long long* order, int B,
                                        int L, int V, int C, void* dtokens, void* dpos, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!order || !dtokens || !dpos || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;
+    if (!order || !dpos || B < 0 || L < 1 || V < 0 || V > L || C < 8) return GM3D_EINVAL;       // dtokens may be NULL
     if (C % 8) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;

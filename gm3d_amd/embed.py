@@ -70,7 +70,13 @@ def _c32(p):
 
 class EmbedFn(torch.autograd.Function):
     """args: nb (B,G,K,3) f32, meta, w1,b1,g1,be1, w2,b2, w3,b3,g2,be2, w4,b4, then the BatchNorm buffers
-    rm1,rv1,nbt1, rm2,rv2,nbt2 (updated in place in train mode).  Returns tokens (B,G,C4) in meta['adt']."""
+    rm1,rv1,nbt1, rm2,rv2,nbt2 (updated in place in train mode).  Returns tokens (B,G,C4) in meta['adt'].
+
+    meta['vis_ids'] (B,V) int64 (optional; a strided view of a (B,L) buffer is fine): only these groups' tokens are wanted --
+    the student keeps 25 of 64 (x_vis = tokens[~mask], P/models_mae_learn_loss.py:298) and nothing reads the other 39.  Every
+    layer up to and including the second BatchNorm's statistics still runs over all rows (the statistics, and the running
+    buffers, are those of the full batch); BN-apply + ReLU, the last conv and its max-pool run on the selected groups only,
+    and so do that conv's input- and weight-gradient GEMMs (the dropped rows' gradient is exactly zero).  Returns (B,V,C4)."""
 
     @staticmethod
     def forward(ctx, nb, meta, w1, b1, g1, be1, w2, b2, w3, b3, g2, be2, w4, b4, rm1, rv1, nbt1, rm2, rv2, nbt2):
@@ -139,9 +145,21 @@ class EmbedFn(torch.autograd.Function):
         _launch("gm3d_bn_finalize", {"C": C3}, lib.gm3d_bn_finalize, _ptr(st), float(R), _ptr(g2c), _ptr(be2c), eps, mom,
                 _ptr(rm2), _ptr(rv2), _ptr(nbt2), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), C3, int(training),
                 _stream())
-        a2 = torch.empty(R, C3, dtype=adt, device=dev)
-        _launch("gm3d_bn_bcast_apply_relu", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
-                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), BG, K, C3, 0.0, dt_id, _stream())
+        vis = meta.get("vis_ids")
+        sel = inv = None
+        BGs, Gs = BG, G                       # groups that go through conv4
+        if vis is not None:
+            if vis.dim() != 2 or vis.shape[0] != B or vis.dtype != torch.int64 or vis.stride(1) != 1 or vis.shape[1] > G:
+                raise ValueError("vis_ids must be (B,V) int64 with unit inner stride, V <= G")
+            Gs = vis.shape[1]
+            BGs = B * Gs
+            sel = torch.empty(BGs, dtype=torch.int32, device=dev)
+            inv = torch.empty(BG, dtype=torch.int32, device=dev)
+            _launch("gm3d_group_select_maps", {"B": B, "V": Gs, "G": G}, lib.gm3d_group_select_maps, _ptr(vis), vis.stride(0), B,
+                    Gs, G, _ptr(sel), _ptr(inv), _stream())
+        a2 = torch.empty(BGs * K, C3, dtype=adt, device=dev)
+        _launch("gm3d_bn_bcast_apply_relu", {"G": BGs, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu_sel,
+                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), _ptr(sel), BGs, K, C3, 0.0, dt_id, _stream())
         # ---- conv4 + max-pool ----
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         b4f = _c32(b4)
@@ -150,17 +168,18 @@ class EmbedFn(torch.autograd.Function):
             _, tok, arg2 = gemm.linear_pool(a2, W4, b4f, bias_after_pool=True, want_rows=False)
         else:
             z = a2 @ W4.t()
-            tok = torch.empty(BG, C4, dtype=adt, device=dev)
-            arg2 = torch.empty(BG, C4, dtype=torch.uint8, device=dev)
-            _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
-                    _ptr(b4f), _ptr(tok), _ptr(arg2), BG, K, C4, dt_id, _stream())
+            tok = torch.empty(BGs, C4, dtype=adt, device=dev)
+            arg2 = torch.empty(BGs, C4, dtype=torch.uint8, device=dev)
+            _launch("gm3d_group_max_fwd", {"G": BGs, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
+                    _ptr(b4f), _ptr(tok), _ptr(arg2), BGs, K, C4, dt_id, _stream())
         if meta["grad"] and any(ctx.needs_input_grad):
             if not training:
                 raise NotImplementedError("EmbedFn backward is implemented for train-mode BatchNorm only")
             ctx.save_for_backward(x, a1, f, fg, arg1, y0, t, a2, arg2, w1, b1, g1, w2, w3, g2, w4, mcov, xmean,
                                   mean1, rstd1, mean2, rstd2, scale2, shift2)
             ctx.meta, ctx.dims = meta, (B, G, K, C1, C2, C3, C4)
-        return tok.view(B, G, C4)
+            ctx.sel, ctx.inv, ctx.Gs = sel, inv, Gs
+        return tok.view(B, Gs, C4)
 
     @staticmethod
     def backward(ctx, dtok):
@@ -177,28 +196,29 @@ class EmbedFn(torch.autograd.Function):
         BG, R = B * G, B * G * K
         dev = dtok.device
         f64 = torch.float64
-        dtok = dtok.reshape(BG, C4).to(adt).contiguous()
+        sel, inv, BGs = ctx.sel, ctx.inv, B * ctx.Gs         # conv4 saw BGs groups (all of them when sel is None)
+        dtok = dtok.reshape(BGs, C4).to(adt).contiguous()
         db4 = colsum(dtok, adt)
         # conv4
-        dz = torch.empty(R, C4, dtype=adt, device=dev)
-        _launch("gm3d_group_max_bwd", {"G": BG, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_bwd, _ptr(dtok),
-                _ptr(arg2), _ptr(dz), BG, K, C4, dt_id, _stream())
+        dz = torch.empty(BGs * K, C4, dtype=adt, device=dev)
+        _launch("gm3d_group_max_bwd", {"G": BGs, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_bwd, _ptr(dtok),
+                _ptr(arg2), _ptr(dz), BGs, K, C4, dt_id, _stream())
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         da2 = dz @ W4
         dW4 = splitk_wgrad(dz, a2)
-        # BN2 + ReLU
-        nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
+        # BN2 + ReLU: the sums run over the rows that carry a gradient, dy is written for every row
+        nrows = lib.gm3d_embed_partial_rows(1, BGs, C3)
         part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
-        _launch("gm3d_bn_bcast_bwd_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats,
-                _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), BG, K, C3, _ptr(part),
-                0.0, dt_id, _stream())
+        _launch("gm3d_bn_bcast_bwd_stats", {"G": BGs, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats_sel,
+                _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), _ptr(sel), BGs, K, C3,
+                _ptr(part), 0.0, dt_id, _stream())
         s12 = _finish(part, nrows, 2 * C3)
         s1, s2 = s12[:C3], s12[C3:]
         dy = torch.empty(R, C3, dtype=adt, device=dev)
         dt = torch.empty(BG, C3, dtype=torch.float32, device=dev)
-        _launch("gm3d_bn_bcast_bwd_apply", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply,
+        _launch("gm3d_bn_bcast_bwd_apply", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply_sel,
                 _ptr(da2), _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), _ptr(s1), _ptr(s2),
-                _ptr(dy), _ptr(dt), BG, K, C3, 0.0, dt_id, _stream())
+                _ptr(dy), _ptr(dt), _ptr(inv), BG, K, C3, 0.0, dt_id, _stream())
         dg2, dbe2 = s2, s1
         # conv3: local part on rows, global part per group
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
@@ -242,14 +262,15 @@ class EmbedFn(torch.autograd.Function):
                 dW4.reshape(w4.shape), db4, None, None, None, None, None, None)
 
 
-def run_embed(enc, point_groups):
-    """enc: the Encoder module (parameters in the reference's Conv1d/BatchNorm1d layout)."""
+def run_embed(enc, point_groups, vis_ids=None):
+    """enc: the Encoder module (parameters in the reference's Conv1d/BatchNorm1d layout).  vis_ids (B,V) int64: embed only these
+    groups' tokens -> (B,V,C) (see EmbedFn)."""
     c0, bn0, _, c1 = enc.first_conv
     c2, bn1, _, c3 = enc.second_conv
     adt = torch.bfloat16 if (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16) \
         else torch.float32
     meta = {"adt": adt, "training": enc.training, "eps": bn0.eps, "momentum": bn0.momentum,
-            "grad": torch.is_grad_enabled()}
+            "grad": torch.is_grad_enabled(), "vis_ids": vis_ids}
     return EmbedFn.apply(point_groups, meta, c0.weight, c0.bias, bn0.weight, bn0.bias, c1.weight, c1.bias, c2.weight,
                          c2.bias, bn1.weight, bn1.bias, c3.weight, c3.bias, bn0.running_mean, bn0.running_var,
                          bn0.num_batches_tracked, bn1.running_mean, bn1.running_var, bn1.num_batches_tracked)

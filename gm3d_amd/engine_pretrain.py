@@ -587,11 +587,14 @@ class SegmentedDDPStep:
                 mask, vis_ids, mask_ids = teacher.generate_mask_ids(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True,
                                                                     epoch=epoch, total_epoch=args.epochs, noise=self.static_noise)
                 bool_masked_pos = mask.flatten(1).to(torch.bool)
-            tokens = raw.encoder(group[0])                    # segment 2 | segment 1 boundary: the encoder sees detached leaves
+            from . import models_mae_learn_loss as MM
+            vis_only = MM.VISIBLE_EMBED and raw.encoder.fused(group[0]) and vis_ids.shape[1] < L
+            # segment 2 | segment 1 boundary: the encoder sees detached leaves (the visible tokens only, when the embed can stop there)
+            tokens = raw.encoder(group[0], vis_ids=vis_ids if vis_only else None)
             pos_all = raw.embed_pos(group[1])
             tokens_d, pos_all_d = tokens.detach().requires_grad_(True), pos_all.detach().requires_grad_(True)
             outs = self.model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens_d, pos_all=pos_all_d,
-                              ids=(vis_ids, mask_ids), cut=True)
+                              ids=(vis_ids, mask_ids), cut=True, tokens_visible=vis_only)
             M = outs["mask_num"]
             loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"], mask_ids=mask_ids)
             loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]

@@ -247,6 +247,49 @@ class TokenAssembleFn(torch.autograd.Function):
         return dtokens, dpos, None, None
 
 
+class PosAssembleFn(torch.autograd.Function):
+    """TokenAssembleFn without the token half (the tokens were embedded for the visible groups only): pos (B,L,C), order ->
+    pos_vis (B,V,C), pos_full (B,L,C)."""
+
+    @staticmethod
+    def forward(ctx, pos, order, V, dt):
+        B, L, C = pos.shape
+        pos = pos.to(dt).contiguous()
+        order = order.contiguous()
+        pos_vis = torch.empty(B, V, C, dtype=dt, device=pos.device)
+        pos_full = torch.empty(B, L, C, dtype=dt, device=pos.device)
+        _launch("gm3d_token_assemble_fwd", {"B": B, "L": L, "C": C}, lib.gm3d_token_assemble_fwd, None, _ptr(pos), _ptr(order),
+                B, L, V, C, None, _ptr(pos_vis), _ptr(pos_full), _DT[dt], _stream())
+        ctx.save_for_backward(order)
+        ctx.dims, ctx.dt = (B, L, V, C), dt
+        return pos_vis, pos_full
+
+    @staticmethod
+    def backward(ctx, dpos_vis, dpos_full):
+        (order,) = ctx.saved_tensors
+        B, L, V, C = ctx.dims
+        dt = ctx.dt
+        g = [None if t is None else t.to(dt).contiguous() for t in (dpos_vis, dpos_full)]
+        dpos = torch.empty(B, L, C, dtype=dt, device=order.device)
+        _launch("gm3d_token_assemble_bwd", {"B": B, "L": L, "C": C}, lib.gm3d_token_assemble_bwd, None, _ptr(g[0]), _ptr(g[1]),
+                _ptr(order), B, L, V, C, None, _ptr(dpos), _DT[dt], _stream())
+        return dpos, None, None, None
+
+
+def _order_of(vis_ids, mask_ids):
+    L = vis_ids.shape[1] + mask_ids.shape[1]
+    if (vis_ids.stride(0) == L and vis_ids.stride(1) == 1 and mask_ids.shape[1] and mask_ids.stride(0) == L and
+            mask_ids.data_ptr() == vis_ids.data_ptr() + vis_ids.shape[1] * vis_ids.element_size()):
+        return torch.as_strided(vis_ids, (vis_ids.shape[0], L), (L, 1))      # the two halves of one (B,L) buffer
+    if mask_ids.shape[1] == 0:
+        return vis_ids
+    return torch.cat([vis_ids, mask_ids], dim=1)
+
+
+def pos_assemble(pos, vis_ids, mask_ids, dt=None):
+    return PosAssembleFn.apply(pos, _order_of(vis_ids, mask_ids), vis_ids.shape[1], dt or _adt())
+
+
 def token_assemble(tokens, pos, vis_ids, mask_ids, order=None):
     if order is None:
         L = vis_ids.shape[1] + mask_ids.shape[1]

@@ -72,6 +72,7 @@ _keep_cache = {}
 
 
 PARALLEL_DECODERS = os.environ.get("GM3D_PARALLEL_DECODERS", "0") == "1"
+VISIBLE_EMBED = os.environ.get("GM3D_VISIBLE_EMBED", "1") == "1"   # student: last embed conv on the visible groups only
 _decoder_streams = {}
 
 
@@ -162,11 +163,18 @@ class Encoder(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(512, 512, 1), nn.BatchNorm1d(512), nn.ReLU(inplace=True),
                                          nn.Conv1d(512, self.encoder_channel, 1))
 
-    def forward(self, point_groups):
-        if FUSED_EMBED and point_groups.is_cuda and (self.training or not torch.is_grad_enabled()
-                                                     or not any(p.requires_grad for p in self.parameters())):
+    def fused(self, point_groups):
+        return FUSED_EMBED and point_groups.is_cuda and (self.training or not torch.is_grad_enabled()
+                                                         or not any(p.requires_grad for p in self.parameters()))
+
+    def forward(self, point_groups, vis_ids=None):
+        """vis_ids (B,V) int64 (optional): return only these groups' tokens, (B,V,C) = take(forward(point_groups), vis_ids); the
+        fused path then runs its last conv on those groups alone (embed.EmbedFn)."""
+        if self.fused(point_groups):
             from . import embed
-            return embed.run_embed(self, point_groups)
+            return embed.run_embed(self, point_groups, vis_ids=vis_ids)
+        if vis_ids is not None:
+            return take(self.forward(point_groups), vis_ids)
         bs, g, n, _ = point_groups.shape
         c0, bn0, _, c1 = self.first_conv
         c2, bn1, _, c3 = self.second_conv
@@ -348,13 +356,14 @@ class MaskedAutoencoderViT(nn.Module):
         return (F.linear(h, w.unsqueeze(0)).squeeze(-1) + c1.bias.mean()).view(B, L)
 
     def forward(self, pts, mask, noaug=False, num_visible=None, group=None, need_pix_pred=True, tokens=None,
-                pos_all=None, ids=None, cut=False):
+                pos_all=None, ids=None, cut=False, tokens_visible=False):
         """pts (B,N,3) f32, mask (B,64) bool (True = masked).  Extra keyword-only conveniences for the
         engine: `num_visible` (static visible count, avoids a host sync), `group` (a previously
         computed (neighborhood, center, neighborhood_org), e.g. the teacher's -- the student sees the
         identical samples), `need_pix_pred=False` (skip the reconstruction decoder whose output the
         teacher pass never reads, P/engine_pretrain.py:86-94), `tokens` / `pos_all` (this model's token embed and
-        positional embed of all 64 groups when the engine has already evaluated them -- neither depends on the mask)."""
+        positional embed of all 64 groups when the engine has already evaluated them -- neither depends on the mask;
+        tokens_visible=True: `tokens` is (B,V,C), already restricted to the visible groups in vis_ids order)."""
         neighborhood, center, neighborhood_org = group if group is not None else self.group_divider(pts)
         vis_ids, mask_ids = ids if ids is not None else split_ids(mask, num_visible)   # ids: precomputed (generate_mask_ids)
         if pos_all is None:
@@ -363,10 +372,20 @@ class MaskedAutoencoderViT(nn.Module):
         if FUSED_HEADS and pos_all.is_cuda:
             # visible-token gather, its positional gather and the [visible | masked] positional concat in one launch
             from . import heads
+            if tokens is None and VISIBLE_EMBED and vis_ids.shape[1] < self.num_group and self.encoder.fused(neighborhood):
+                # the mask is known: embed the visible groups only (the other 39 tokens of the reference's x = encoder(...) are
+                # never read, P/:298) -- same values, 61 % less work in the last conv and its backward
+                tokens, tokens_visible = self.encoder(neighborhood, vis_ids=vis_ids), True
             if tokens is None:
                 tokens = self.encoder(neighborhood)
-            tok_vis, pos_vis, pos_full = heads.token_assemble(tokens, pos_all, vis_ids, mask_ids)
+            if tokens_visible:
+                pos_vis, pos_full = heads.pos_assemble(pos_all, vis_ids, mask_ids)
+                tok_vis = tokens
+            else:
+                tok_vis, pos_vis, pos_full = heads.token_assemble(tokens, pos_all, vis_ids, mask_ids)
             x_vis = self.blocks(tok_vis, pos_vis, norm=self.norm_p)
+        elif tokens_visible:
+            x_vis = self.blocks(tokens, take(pos_all, vis_ids), norm=self.norm_p)
         else:
             x_vis = self._encode_visible(neighborhood, vis_ids, pos_all, tokens)
         B, _, C = x_vis.shape

@@ -190,6 +190,24 @@ int gm3d_bn_bcast_bwd_apply(const void *da2, const void *y0, const void *t, cons
                             const float *mean, const float *rstd, const float *s1, const float *s2, void *dy,
                             float *dt, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
 
+/* The same three passes when only a SUBSET of the groups goes on to the next layer -- the student's visible tokens: x_vis =
+ * tokens[~mask] (models_mae_learn_loss.py:298) discards 39 of 64 groups per cloud after the last conv + max-pool, so that conv
+ * (and its backward) only needs the visible groups' rows, while the batch statistics still cover every row.
+ * gm3d_group_select_maps: ids (B,V) int64 (row pitch id_pitch) -> sel (B*V) = flat source group of every selected group and
+ * inv (B*G) = position in sel, or -1.  _apply_relu_sel: a2 holds the G selected groups (compact), read from groups sel[g] of
+ * y0 / t.  _bwd_stats_sel: da2 holds the G selected groups (the others' gradient is zero and contributes nothing to the sums).
+ * _bwd_apply_sel: all G groups are written; da2 of group g is row block inv[g] of the compact buffer, zero when inv[g] < 0.
+ * sel / inv NULL = the plain forms above. */
+int gm3d_group_select_maps(const long long *ids, int id_pitch, int B, int V, int G, int *sel, int *inv, gm3d_stream_t stream);
+int gm3d_bn_bcast_apply_relu_sel(const void *y0, const void *t, const float *scale, const float *shift, void *a2,
+                                 const int *sel, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
+int gm3d_bn_bcast_bwd_stats_sel(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
+                                const float *mean, const float *rstd, const int *sel, int G, int K, int C, float *partial,
+                                float slope, int dtype, gm3d_stream_t stream);
+int gm3d_bn_bcast_bwd_apply_sel(const void *da2, const void *y0, const void *t, const float *scale, const float *shift,
+                                const float *mean, const float *rstd, const float *s1, const float *s2, void *dy, float *dt,
+                                const int *inv, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
+
 /* df (G,K,C) += dfg (G,C) at k == arg (in place); partial[row][c] = column sums of the result. */
 int gm3d_group_scatter_add(void *df, const void *dfg, const uint8_t *arg, int G, int K, int C, float *partial,
                            int dtype, gm3d_stream_t stream);
@@ -297,7 +315,8 @@ int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows,
 /* Token / positional-embedding assembly around the mask (models_mae_learn_loss.py:298-300,649-658) in one pass each way.
  * order (B,L) int64 = [visible ids | masked ids], a permutation of 0..L-1 per sample (gm3d_mask_select writes exactly this when its
  * two id outputs are the halves of one (B,L) buffer).  fwd: x_vis, pos_vis (B,V,C) and pos_full (B,L,C) gathered from tokens / pos
- * (B,L,C).  bwd: dtokens, dpos (B,L,C) from dx_vis, dpos_vis (B,V,C) and dpos_full (B,L,C) (any may be NULL = zero). */
+ * (B,L,C).  bwd: dtokens, dpos (B,L,C) from dx_vis, dpos_vis (B,V,C) and dpos_full (B,L,C) (any may be NULL = zero).
+ * tokens and x_vis both NULL (fwd) / dtokens NULL (bwd): positions only -- the tokens were embedded for the visible groups alone. */
 int gm3d_token_assemble_fwd(const void *tokens, const void *pos, const long long *order, int B, int L, int V, int C, void *x_vis,
                             void *pos_vis, void *pos_full, int dtype, gm3d_stream_t stream);
 int gm3d_token_assemble_bwd(const void *dx_vis, const void *dpos_vis, const void *dpos_full, const long long *order, int B, int L,

@@ -76,3 +76,59 @@ def test_splitk_wgrad_and_colsum():
         ref = dy.double().t() @ x.double()
         assert rel(embed.splitk_wgrad(dy, x), ref) <= 1e-5
         assert rel(embed.colsum(dy.contiguous(), adt), dy.double().sum(0)) <= 1e-5
+
+
+@pytest.mark.parametrize("B,G,V,bf16", [(4, 64, 25, False), (4, 64, 25, True), (3, 16, 5, False), (2, 64, 64, False)])
+def test_visible_only_embed(B, G, V, bf16):
+    """Encoder(nb, vis_ids) -- BN-apply, the last conv and its max-pool on the visible groups only -- against
+    take(Encoder(nb), vis_ids): tokens (the same dot products; a library GEMM may tile the smaller matrix differently), every parameter gradient (the dropped rows'
+    gradient is exactly zero; only the summation order of the weight gradient differs) and the running statistics (still those
+    of the full batch).  vis_ids is a strided view of an (B,L) order buffer, unsorted, as the mask kernel produces it."""
+    from gm3d_amd import models_mae_learn_loss as M
+    from gm3d_amd.models_mae_learn_loss import take
+    torch.manual_seed(7 + V)
+    base = M.Encoder(384).cuda()
+    with torch.no_grad():
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    nb = torch.randn(B, G, 32, 3, device="cuda") * 0.2
+    order = torch.stack([torch.randperm(G, device="cuda") for _ in range(B)])          # (B,G) int64
+    vis = order[:, :V]
+    assert vis.stride(0) == G
+    w = torch.randn(B, V, 384, device="cuda")
+
+    def run(selected):
+        enc = copy.deepcopy(base).train()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
+            tok = enc(nb, vis_ids=vis) if selected else take(enc(nb), vis)
+            (tok.float() * w).sum().backward()
+        return (tok.detach(), {k: p.grad.detach().double() for k, p in enc.named_parameters()},
+                {k: b.detach().double().clone() for k, b in enc.named_buffers()})
+
+    tok_f, g_f, b_f = run(False)
+    tok_s, g_s, b_s = run(True)
+    assert tok_s.shape == (B, V, 384)
+    assert _err(tok_s.double(), tok_f.double()) <= (8e-3 if bf16 else 1e-5) * float(tok_f.abs().max())
+    gnorm = sum(float(v.pow(2).sum()) for v in g_f.values()) ** 0.5
+    tol = 2e-2 if bf16 else 2e-5        # bf16: da2 is rounded to bf16 in both runs, the weight-gradient partial sums differ
+    for k in g_f:
+        assert _err(g_s[k], g_f[k]) <= tol * float(g_f[k].abs().max()) + 1e-6 * gnorm, k
+    for k in b_f:
+        assert torch.equal(b_s[k], b_f[k]), k
+
+
+def test_group_select_maps():
+    from gm3d_amd._capi import check, lib
+    from gm3d_amd.ops import _ptr, _stream
+    B, G, V = 5, 64, 25
+    order = torch.stack([torch.randperm(G, device="cuda") for _ in range(B)])
+    sel = torch.empty(B * V, dtype=torch.int32, device="cuda")
+    inv = torch.empty(B * G, dtype=torch.int32, device="cuda")
+    check(lib.gm3d_group_select_maps(_ptr(order), G, B, V, G, _ptr(sel), _ptr(inv), _stream()), "maps")
+    want_sel = (order[:, :V] + torch.arange(B, device="cuda")[:, None] * G).reshape(-1).int()
+    assert torch.equal(sel, want_sel)
+    want_inv = torch.full((B * G,), -1, dtype=torch.int32, device="cuda")
+    want_inv[want_sel.long()] = torch.arange(B * V, dtype=torch.int32, device="cuda")
+    assert torch.equal(inv, want_inv)
+    assert lib.gm3d_group_select_maps(_ptr(order), V - 1, B, V, G, _ptr(sel), _ptr(inv), _stream()) != 0      # pitch < V
