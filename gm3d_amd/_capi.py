@@ -44,6 +44,11 @@ SIGNATURES = {
     "gm3d_bn_bcast_apply_relu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_bn_bcast_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp],
     "gm3d_bn_bcast_bwd_apply": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gm3d_head_fold": [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp],
+    "gm3d_head_rowdot": [_vp, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_head_fold_bwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_head_outer": [_vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_scale_translate": [_vp, _vp, _f, _f, _f, _i, _i, _vp],
     "gm3d_group_select_maps": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "gm3d_bn_bcast_apply_relu_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_bn_bcast_bwd_stats_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _f, _i, _vp],

@@ -655,6 +655,120 @@ __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict
 // for all j -- the boolean-mask gathers and the concat of P/models_mae_learn_loss.py:298-300,649-658 in one pass.
 // Backward: because `order` is a permutation every source row is written exactly once (no atomics, no zero fill):
 // dtokens[b,order[b,j]] = j < V ? dx_vis[b,j] : 0 ; dpos[b,order[b,j]] = dpos_full[b,j] + (j < V ? dpos_vis[b,j] : 0).
+// ------------------------------------------------------------------ loss-predictor head tail (increase_dim_2[3] + mean(-1), :152-158,677)
+// The last Conv1d(C -> nout) followed by the mean over its nout outputs is one C-vector: wv[c] = mean_o W1[o][c], bm = mean_o b1[o].
+// head_fold: wv (f32 and T copies) + bm.  Workgroup = 16 columns x 16 row slices (C/16 workgroups: the matrix is small, the
+// point is to spread its nout x C loads over many CUs); the last workgroup also averages the bias.
+template <class T>
+__global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict__ W1, const float* __restrict__ b1, int nout, int C,
+                                                        float* __restrict__ wv, T* __restrict__ wv_t, float* __restrict__ bm) {
+    __shared__ float red[256];
+    const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+    if ((int)blockIdx.x * 16 < C) {
+        const int c = blockIdx.x * 16 + cx;
+        float s = 0.f;
+        if (c < C)
+            for (int o = ry; o < nout; o += 16) s += W1[(size_t)o * C + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (ry == 0 && c < C) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += red[k * 16 + cx];
+            t *= 1.0f / (float)nout;
+            wv[c] = t;
+            wv_t[c] = (T)t;
+        }
+    } else {                       // the extra workgroup: bm = mean(b1)
+        float s = 0.f;
+        for (int o = threadIdx.x; o < nout; o += blockDim.x) s += b1[o];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) bm[0] = red[0] / (float)nout;
+    }
+}
+
+// out[r] = T-rounded(a[r,:] . wv) + bm : one wave per row (C % 8 == 0)
+template <class T>
+__global__ __launch_bounds__(256) void head_rowdot_kernel(const T* __restrict__ a, const T* __restrict__ wv, const float* __restrict__ bm,
+                                                          int R, int C, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const float b = bm[0];
+    for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane * 8; c < C; c += 512) {
+            float x[8], y[8];
+            V8<T>::load(a + (size_t)r * C + c, x);
+            V8<T>::load(wv + c, y);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += x[i] * y[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) out[r] = (float)(T)s + b;
+    }
+}
+
+// backward of the fold: dW1[o][c] = dwv[c] / nout (elementwise over nout*C), db1[o] = sum_r d[r] / nout (the extra, last workgroup)
+__global__ __launch_bounds__(256) void head_fold_bwd_kernel(const float* __restrict__ dwv, const float* __restrict__ d, int R, int nout,
+                                                            int C, int ew_blocks, float* __restrict__ dW1, float* __restrict__ db1) {
+    if ((int)blockIdx.x < ew_blocks) {
+        const size_t total = (size_t)nout * C;
+        const float inv = 1.0f / (float)nout;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)ew_blocks * blockDim.x)
+            dW1[i] = dwv[i % C] * inv;
+        return;
+    }
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) s += d[r];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    const float g = red[0] / (float)nout;
+    for (int o = threadIdx.x; o < nout; o += blockDim.x) db1[o] = g;
+}
+
+// da[r][c] = T(d[r] * wv[c])
+template <class T>
+__global__ __launch_bounds__(256) void head_outer_kernel(const float* __restrict__ d, const float* __restrict__ wv, int R, int C,
+                                                         T* __restrict__ da) {
+    const int tpr = C >> 3;
+    const size_t total = (size_t)R * tpr;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t r = i / tpr;
+        const int c = (int)(i - r * tpr) * 8;
+        const float dr = d[r];
+        float v[8];
+        V8<float>::load(wv + c, v);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] *= dr;
+        V8<T>::store(da + r * C + c, v);
+    }
+}
+
+// PointcloudScaleAndTranslate (datasets/data_transforms.py:20-35) on the device, in place: u (2,B,3) uniform draws ->
+// scale = u0*span+lo, shift = (u1*2-1)*t, p = p*scale + shift, every product and sum rounded separately (the same
+// values as the elementwise-op chain it replaces).
+__global__ __launch_bounds__(256) void scale_translate_kernel(float* __restrict__ pc, const float* __restrict__ u, float lo, float span,
+                                                              float t, int B, int N) {
+#pragma clang fp contract(off)   // products and sums rounded separately, like the op chain (HIP's __fmul_rn is a contractable `*`)
+    const long long total = (long long)B * N * 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / ((long long)N * 3)), j = (int)(i % 3);
+        const float sc = u[b * 3 + j] * span + lo;
+        const float sh = (u[(B + b) * 3 + j] * 2.0f - 1.0f) * t;
+        pc[i] = pc[i] * sc + sh;
+    }
+}
+
 // ids (B, V) int64 with row pitch `pitch` (the visible ids of every cloud) -> sel[b*V + v] = b*G + ids[b][v] (selected group list)
 // and inv[b*G + g] = position of group g in that list, -1 when it is not selected.  One workgroup per cloud.
 __global__ __launch_bounds__(256) void group_select_maps_kernel(const long long* __restrict__ ids, int pitch, int V, int G,
@@ -892,6 +1006,76 @@ extern "C" int gm3d_bn_bcast_bwd_apply(const void* da2, const void* y0, const vo
                                        const float* s2, void* dy, float* dt, int G, int K, int C, float slope, int dtype,
                                        gm3d_stream_t stream) {
     return gm3d_bn_bcast_bwd_apply_sel(da2, y0, t, scale, shift, mean, rstd, s1, s2, dy, dt, nullptr, G, K, C, slope, dtype, stream);
+}
+
+extern "C" int gm3d_head_fold(const float* W1, const float* b1, int nout, int C, float* wv, void* wv_t, float* bm, int dtype,
+                              gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!W1 || !b1 || !wv || !wv_t || !bm || nout < 1 || C < 1) return GM3D_EINVAL;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int grid = (C + 15) / 16 + 1;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(head_fold_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, W1, b1, nout, C, wv, (bf16_t*)wv_t, bm),
+                  hipLaunchKernelGGL(head_fold_kernel<float>, dim3(grid), dim3(256), 0, st, W1, b1, nout, C, wv, (float*)wv_t, bm));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_head_rowdot(const void* a, const void* wv_t, const float* bm, int R, int C, float* out, int dtype,
+                                gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!a || !wv_t || !bm || !out || R < 0) return GM3D_EINVAL;
+    if (C < 8 || C % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (R + 3) / 4; grid = grid > 4096 ? 4096 : grid;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(head_rowdot_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)wv_t, bm, R, C, out),
+                  hipLaunchKernelGGL(head_rowdot_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)a, (const float*)wv_t, bm, R, C, out));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_head_fold_bwd(const float* dwv, const float* d, int R, int nout, int C, float* dW1, float* db1,
+                                  gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dwv || !d || !dW1 || !db1 || R < 1 || nout < 1 || C < 1) return GM3D_EINVAL;
+    long long ew = ((long long)nout * C + 255) / 256;
+    const int ew_blocks = (int)(ew > 2048 ? 2048 : ew);
+    hipLaunchKernelGGL(head_fold_bwd_kernel, dim3(ew_blocks + 1), dim3(256), 0, (hipStream_t)stream, dwv, d, R, nout, C, ew_blocks, dW1,
+                       db1);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_head_outer(const float* d, const float* wv, int R, int C, void* da, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!d || !wv || !da || R < 0) return GM3D_EINVAL;
+    if (C < 8 || C % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t total = (size_t)R * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(head_outer_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, d, wv, R, C, (bf16_t*)da),
+                  hipLaunchKernelGGL(head_outer_kernel<float>, dim3(grid), dim3(256), 0, st, d, wv, R, C, (float*)da));
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_scale_translate(float* pc, const float* u, float lo, float span, float t, int B, int N, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!pc || !u || B < 0 || N < 0) return GM3D_EINVAL;
+    const long long total = (long long)B * N * 3;
+    if (total == 0) return GM3D_OK;
+    long long grid = (total + 255) / 256;
+    hipLaunchKernelGGL(scale_translate_kernel, dim3((unsigned)(grid > 2048 ? 2048 : grid)), dim3(256), 0, (hipStream_t)stream, pc, u, lo, span,
+                       t, B, N);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
 }
 
 extern "C" int gm3d_group_select_maps(const long long* ids, int id_pitch, int B, int V, int G, int* sel, int* inv,

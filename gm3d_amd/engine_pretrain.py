@@ -53,6 +53,13 @@ class PointcloudScaleAndTranslate(object):
 
     def __call__(self, pc, draws=None, generator=None):
         B = pc.size(0)
+        if draws is None and pc.is_cuda and pc.dtype == torch.float32 and pc.dim() == 3 and pc.size(2) == 3 and pc.is_contiguous():
+            from ._capi import check, lib            # one launch after the draw (the same arithmetic, rounded the same way)
+            from .ops import _ptr, _stream
+            u = torch.rand(2, B, 3, device=pc.device, generator=generator)
+            check(lib.gm3d_scale_translate(_ptr(pc), _ptr(u), self.scale_low, self.scale_high - self.scale_low, self.translate_range, B, pc.size(1),
+                                           _stream()), "gm3d_scale_translate")
+            return pc
         if draws is None:
             u = torch.rand(2, B, 3, device=pc.device, generator=generator)
             scale = u[0] * (self.scale_high - self.scale_low) + self.scale_low
@@ -138,6 +145,7 @@ class ModelEma:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._pairs = None
+        self._int_flat = None
 
     def _build(self, model):
         msd = model.state_dict()
@@ -150,6 +158,18 @@ class ModelEma:
             mv = msd["module." + k if needs_module else k]
             (fe if v.dtype.is_floating_point else ie).append(v)
             (fm if v.dtype.is_floating_point else im).append(mv)
+        self._int_flat = None
+        if ie and ie[0].is_cuda:
+            # the integer counters (BatchNorm num_batches_tracked, 0-dim int64) of each model become views of ONE tensor, so that
+            # their update is 4 launches in all instead of 5 per counter; every in-place user (nn.BatchNorm1d, gm3d_bn_finalize,
+            # load_state_dict, the buffer broadcast) keeps working on the views
+            eb, mb = dict(self.ema.named_buffers()), {k[7:] if k.startswith("module.") else k: b for k, b in model.named_buffers()}
+            keys = [k for k, b in eb.items() if b.dtype == torch.int64 and b.dim() == 0 and k in mb and mb[k].dtype == torch.int64]
+            if len(keys) == len(ie):
+                E, Mv = torch.stack([eb[k] for k in keys]), torch.stack([mb[k] for k in keys])
+                for j, k in enumerate(keys):
+                    eb[k].data, mb[k].data = E[j], Mv[j]
+                self._int_flat, ie, im = (E, Mv), [], []
         self._pairs = (fe, fm, ie, im)
 
     @torch.no_grad()
@@ -161,6 +181,9 @@ class ModelEma:
             torch._foreach_lerp_(fe, fm, 1.0 - self.decay)  # v + (1-decay)*(m - v): one multi-tensor pass
         for e, m in zip(ie, im):
             e.copy_((e * self.decay + (1.0 - self.decay) * m).to(e.dtype))
+        if self._int_flat is not None:
+            E, Mv = self._int_flat
+            E.copy_(E * self.decay + (1.0 - self.decay) * Mv)      # the same fp32 expression, truncated by the converting copy
 
 
 def ema_decay_for_epoch(epoch):

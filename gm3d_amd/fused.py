@@ -257,10 +257,15 @@ class TransformerStackFn(torch.autograd.Function):
         nblk = len(params) // PER_BLOCK
         adt, H, scale, eps = meta["adt"], meta["num_heads"], meta["scale"], meta["eps"]
         R = B * T
-        res = x.reshape(R, C).float().contiguous()
         posa = pos.reshape(R, C).to(adt).contiguous()
         need = meta["grad"] and any(ctx.needs_input_grad)   # grad mode is off inside forward: captured by run_stack
         y = bias = rs = None
+        if x.dtype == adt and adt != torch.float32:
+            # tokens already in the activation dtype: the first LayerNorm pass reads them as its branch operand (u = x + pos) --
+            # no fp32 copy of the input
+            res, y = None, x.reshape(R, C).contiguous()
+        else:
+            res = x.reshape(R, C).float().contiguous()
         saved = []
         dev = x.device
         if need:  # operands of the weight-gradient GEMMs, stacked over blocks for the batched wgrad
@@ -337,7 +342,10 @@ class TransformerStackFn(torch.autograd.Function):
         G, d_o, _ = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1],
                                     partial=PLN[2 * nblk])
         g_final_w, g_final_b, db2 = SLN[2 * nblk, 0], SLN[2 * nblk, 1], SLN[2 * nblk, 2]
-        dpos = torch.zeros(R, C, dtype=torch.float32, device=dev)
+        # gradient of the positional embedding = sum over blocks of the gradient at every u = x + pos site.  The first site's gradient
+        # (G of the last block) starts the sum: that buffer's only other reader, the next block's LayerNorm-2 backward, has run
+        # by the time the next site accumulates into it -- no zero fill, no read-modify-write for the first site.
+        dpos = torch.zeros(R, C, dtype=torch.float32, device=dev) if nblk == 1 else None
         for i in range(nblk - 1, -1, -1):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             u, m1, r1, qkv, lse, x1, m2, r2, f = saved[i * 9:(i + 1) * 9]
@@ -362,6 +370,8 @@ class TransformerStackFn(torch.autograd.Function):
             dh1 = dqkv @ weight_cache.get(wqkv, adt)
             G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
                                         dy=DO[i - 1] if i > 0 else None, partial=PLN[2 * i])
+            if dpos is None:
+                dpos = G
             gi[0], gi[1] = SLN[2 * i, 0], SLN[2 * i, 1]
             db2 = SLN[2 * i, 2]
             grads[i * PER_BLOCK:(i + 1) * PER_BLOCK] = gi

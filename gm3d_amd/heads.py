@@ -129,8 +129,13 @@ class LossPredHeadFn(torch.autograd.Function):
             _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
                     _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
             W1 = _c32(w1.reshape(w1.shape[0], C))
-            wv = colsum(W1, torch.float32) * (1.0 / w1.shape[0])   # (C,) mean over the 384 output rows, own two-stage sum
-            out = (a @ wv.to(adt)).float() + b1.detach().float().mean()
+            nout = w1.shape[0]
+            wv, wv_t, bm = torch.empty(C, **f32), torch.empty(C, dtype=adt, device=dev), torch.empty(1, **f32)
+            _launch("gm3d_head_fold", {"C": C}, lib.gm3d_head_fold, _ptr(W1), _ptr(_c32(b1)), nout, C, _ptr(wv), _ptr(wv_t), _ptr(bm),
+                    _DT[adt], _stream())                            # wv = mean over the 384 output rows of W1, bm = mean(b1)
+            out = torch.empty(R, **f32)
+            _launch("gm3d_head_rowdot", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_head_rowdot, _ptr(a), _ptr(wv_t), _ptr(bm), R, C,
+                    _ptr(out), _DT[adt], _stream())
             if meta["grad"] and any(ctx.needs_input_grad):
                 if not training:
                     raise NotImplementedError("LossPredHeadFn backward is implemented for train-mode BatchNorm only")
@@ -149,10 +154,14 @@ class LossPredHeadFn(torch.autograd.Function):
             d = dout.reshape(R).float().contiguous()
             nout = w1.shape[0]
             # out = a @ wv + mean(b1), wv = mean_rows(W1)
-            dwv = (a.t() @ d.to(adt)).float()                                        # (C,)  GEMV, not a reduce_kernel
-            dW1 = (dwv / nout).unsqueeze(0).expand(nout, C).reshape(w1.shape).contiguous()
-            db1 = (d.sum() / nout).expand(nout).contiguous()                       # R <= a few thousand elements
-            da = (d.unsqueeze(1) * wv.unsqueeze(0)).to(adt)                         # (R,C)
+            dwv = (a.t() @ d.to(adt)).float().contiguous()                           # (C,)  GEMV, not a reduce_kernel
+            dW1 = torch.empty(w1.shape, dtype=torch.float32, device=dev)
+            db1 = torch.empty(nout, dtype=torch.float32, device=dev)
+            _launch("gm3d_head_fold_bwd", {"C": C}, lib.gm3d_head_fold_bwd, _ptr(dwv), _ptr(d), R, nout, C, _ptr(dW1), _ptr(db1),
+                    _stream())
+            da = torch.empty(R, C, dtype=adt, device=dev)                            # (R,C) = d (x) wv
+            _launch("gm3d_head_outer", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_head_outer, _ptr(d), _ptr(wv), R, C, _ptr(da),
+                    _DT[adt], _stream())
             nrows = lib.gm3d_embed_partial_rows(1, G, C)
             part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
             _launch("gm3d_bn_bcast_bwd_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats,

@@ -190,6 +190,21 @@ int gm3d_bn_bcast_bwd_apply(const void *da2, const void *y0, const void *t, cons
                             const float *mean, const float *rstd, const float *s1, const float *s2, void *dy,
                             float *dt, int G, int K, int C, float slope, int dtype, gm3d_stream_t stream);
 
+/* Tail of the loss-predictor head increase_dim_2 (models_mae_learn_loss.py:152-158) + `.mean(-1)` (:677): Conv1d(C -> nout) followed by
+ * the mean over its nout outputs is one C-vector.  gm3d_head_fold: wv[c] = mean_o W1[o][c] (f32, and a copy in `dtype`), bm = mean(b1).
+ * gm3d_head_rowdot: out[r] = round_dtype(a[r,:] . wv) + bm.  Backward: gm3d_head_fold_bwd: dW1[o][c] = dwv[c]/nout,
+ * db1[o] = sum_r d[r]/nout;  gm3d_head_outer: da[r][c] = d[r] * wv[c] in `dtype`. */
+int gm3d_head_fold(const float *W1, const float *b1, int nout, int C, float *wv, void *wv_t, float *bm, int dtype,
+                   gm3d_stream_t stream);
+int gm3d_head_rowdot(const void *a, const void *wv_t, const float *bm, int R, int C, float *out, int dtype, gm3d_stream_t stream);
+int gm3d_head_fold_bwd(const float *dwv, const float *d, int R, int nout, int C, float *dW1, float *db1, gm3d_stream_t stream);
+int gm3d_head_outer(const float *d, const float *wv, int R, int C, void *da, int dtype, gm3d_stream_t stream);
+
+/* Training augmentation PointcloudScaleAndTranslate.__call__ (Point-MAE_SA3D/datasets/data_transforms.py:27-35, called at
+ * engine_pretrain.py:78), in place on pc (B,N,3) f32: u (2,B,3) f32 uniform draws in [0,1) -> per-cloud scale = u[0]*span+lo (span = hi-lo),
+ * shift = (u[1]*2-1)*t, p = p*scale + shift. */
+int gm3d_scale_translate(float *pc, const float *u, float lo, float span, float t, int B, int N, gm3d_stream_t stream);
+
 /* The same three passes when only a SUBSET of the groups goes on to the next layer -- the student's visible tokens: x_vis =
  * tokens[~mask] (models_mae_learn_loss.py:298) discards 39 of 64 groups per cloud after the last conv + max-pool, so that conv
  * (and its backward) only needs the visible groups' rows, while the batch statistics still cover every row.

@@ -156,3 +156,19 @@ def test_errors_are_loud(gops):
         gops.fps(torch.zeros(1, 3, 16, device="cuda").transpose(1, 2), 4)  # non-contiguous like upstream
     with pytest.raises(RuntimeError):
         gops.knn(torch.zeros(1, 8, 3, device="cuda"), torch.zeros(1, 2, 3, device="cuda"), 9)  # k > N
+
+
+def test_scale_translate_kernel_equals_op_chain():
+    """The augmentation as one launch (gm3d_scale_translate) against the elementwise-op chain with the same uniform draws."""
+    from gm3d_amd.engine_pretrain import PointcloudScaleAndTranslate
+    aug = PointcloudScaleAndTranslate()
+    pc = torch.randn(7, 1024, 3, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(11)
+    got = aug(pc.clone(), generator=g)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    u = torch.rand(2, 7, 3, device="cuda", generator=g)
+    scale = u[0] * (aug.scale_high - aug.scale_low) + aug.scale_low
+    shift = (u[1] * 2 - 1) * aug.translate_range
+    want = aug(pc.clone(), draws=(scale, shift))
+    assert torch.equal(got, want)
+    assert float(scale.min()) >= 2.0 / 3.0 - 1e-6 and float(scale.max()) <= 1.5 + 1e-6 and float(shift.abs().max()) <= 0.2 + 1e-6
