@@ -406,10 +406,12 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
         loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"],
                                      mask_ids=ids[1] if ids is not None else None)
         loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
-        loss = 13.889 * loss_mse + 1.0 * loss_chfr                      # P/:153
+        # P/:153: 13.889 * MSE + 1.0 * Chamfer; MSE is identically 0 in this variant (no launches, forward or backward, for it)
+        loss = loss_chfr if loss_outs.get("MSE_zero") else 13.889 * loss_mse + 1.0 * loss_chfr
         loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos,
                                                loss_outs["matrix"].detach(), relative=args.relative)
-    total = (loss + loss_learn) / getattr(args, "accum_iter", 1)         # P/:190,195
+    accum = getattr(args, "accum_iter", 1)
+    total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum         # P/:190,195
     flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and optimizer is not None
     if grad_sync is not None and not flat_sync:
         grad_sync.zero_grad()
@@ -621,10 +623,11 @@ class SegmentedDDPStep:
             M = outs["mask_num"]
             loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"], mask_ids=mask_ids)
             loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
-            loss = 13.889 * loss_mse + 1.0 * loss_chfr
+            loss = loss_chfr if loss_outs.get("MSE_zero") else 13.889 * loss_mse + 1.0 * loss_chfr
             loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos, loss_outs["matrix"].detach(),
                                                    relative=args.relative)
-        total = (loss + loss_learn) / getattr(args, "accum_iter", 1)
+        accum = getattr(args, "accum_iter", 1)
+        total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum
         x_vis_d, pos_full_d = outs["features"], outs["pos_full"]   # segment 1 | segment 0 boundary (detached leaves)
         p0 = self.seg_params[0]
         g = torch.autograd.grad(total, p0 + [x_vis_d, pos_full_d], allow_unused=True)
