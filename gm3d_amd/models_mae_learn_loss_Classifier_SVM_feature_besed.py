@@ -50,9 +50,12 @@ class MaskTransformer(nn.Module):
 
     def forward(self, neighborhood, center, mask, num_visible=None, ids=None):
         vis_ids, _ = ids if ids is not None else split_ids(mask, num_visible)
-        tokens = self.encoder(neighborhood)
         pos = _pos_mlp(self.pos_embed, center)
-        return self.blocks(take(tokens, vis_ids), take(pos, vis_ids), norm=self.norm_p)
+        if M.VISIBLE_EMBED and vis_ids.shape[1] < self.num_group and self.encoder.fused(neighborhood):
+            tok_vis = self.encoder(neighborhood, vis_ids=vis_ids)     # last embed conv on the visible groups only (embed.EmbedFn)
+        else:
+            tok_vis = take(self.encoder(neighborhood), vis_ids)
+        return self.blocks(tok_vis, take(pos, vis_ids), norm=self.norm_p)
 
 
 class MaskedAutoencoderViT(nn.Module):
