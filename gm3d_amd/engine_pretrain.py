@@ -582,6 +582,8 @@ class SegmentedDDPStep:
         """gradients of one segment -> their slots of the flat buffer (ONE multi-tensor copy; unused parameters: zeros)."""
         views, have, zero = self.seg_views[seg], [], []
         for v, g in zip(views, grads):
+            if g is not None and g.data_ptr() == v.data_ptr():
+                continue                      # written into its slot by the backward node itself (fused._wgrad_batched)
             (have if g is not None else zero).append((v, g))
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])

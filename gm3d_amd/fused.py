@@ -184,8 +184,9 @@ def _attention_bwd(qkv, out, dout, lse, B, T, H, scale, dqkv=None):
     return dqkv
 
 
-def _wgrad_batched(dy, x):
+def _wgrad_batched(dy, x, out=None):
     """dW[i] = dy[i]^T @ x[i] for every block of a stack in ONE batched GEMM, fp32 result.
+    out (nblk,N,K) f32 (optional): the destination -- the parameters' slots in the optimizer's flat gradient buffer.
     (K = rows is 3200..8192 and the output is only 384..1536 wide: a single such GEMM fills a fraction of the
     256 CUs -- 50 us each through hipBLASLt -- while the batch over blocks runs at ~16 us per block.)"""
     nblk, R, N = dy.shape
@@ -201,7 +202,8 @@ def _wgrad_batched(dy, x):
         # few blocks (the 4-block decoders): nblk * (N/128) * (K/128) tiles do not fill 256 CUs and each runs an 8192-deep
         # reduction -- split the rows S ways into more batches and add the S partial products with the two-stage sum
         part = _wgrad_batched_plain(dy.view(nblk * S, R // S, N), x.view(nblk * S, R // S, K))
-        out = torch.empty(nblk, N, K, dtype=torch.float32, device=dy.device)
+        if out is None:
+            out = torch.empty(nblk, N, K, dtype=torch.float32, device=dy.device)
         if SUM_FEW_ROWS:
             _launch("gm3d_sum_few_rows", {"rows": nblk * S, "cols": N * K}, lib.gm3d_sum_few_rows, _ptr(part), nblk, S, N * K,
                     _ptr(out), _stream())
@@ -209,20 +211,29 @@ def _wgrad_batched(dy, x):
             _launch("gm3d_colsum_finish_batched", {"rows": nblk * S, "cols": N * K}, lib.gm3d_colsum_finish_batched, _ptr(part), nblk,
                     S * N * K, S, N * K, N * K, _ptr(out), N * K, _stream())
         return out
-    return _wgrad_batched_plain(dy, x)
+    return _wgrad_batched_plain(dy, x, out)
 
 
 SUM_FEW_ROWS = __import__("os").environ.get("GM3D_SUM_FEW_ROWS", "1") == "1"
 WGRAD_ROW_SPLIT = int(__import__("os").environ.get("GM3D_WGRAD_SPLIT", "4"))   # 0 = auto, 1 = off, n = fixed n-way for <=4-block stacks
 
 
-def _wgrad_batched_plain(dy, x):
+_BMM_OUT_OK = [True]     # torch.bmm(..., out_dtype=, out=) available?
+
+
+def _wgrad_batched_plain(dy, x, out=None):
     if dy.dtype == torch.float32:
-        return torch.bmm(dy.transpose(1, 2), x)
+        return torch.bmm(dy.transpose(1, 2), x) if out is None else torch.bmm(dy.transpose(1, 2), x, out=out)
+    if out is not None and _BMM_OUT_OK[0]:
+        try:
+            return torch.bmm(dy.transpose(1, 2), x, out_dtype=torch.float32, out=out)
+        except (TypeError, RuntimeError):
+            _BMM_OUT_OK[0] = False
     try:
-        return torch.bmm(dy.transpose(1, 2), x, out_dtype=torch.float32)
+        r = torch.bmm(dy.transpose(1, 2), x, out_dtype=torch.float32)
     except TypeError:
-        return torch.bmm(dy.transpose(1, 2), x).float()
+        r = torch.bmm(dy.transpose(1, 2), x).float()
+    return r if out is None else out.copy_(r)
 
 
 PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
@@ -378,8 +389,14 @@ class TransformerStackFn(torch.autograd.Function):
         finish_batched(PLN, SLN.view(2 * nblk + 1, 3 * C))
         finish_batched(PGL, SGL)
         # all weight gradients of the stack: 4 batched GEMMs
-        gw2, gw1 = _wgrad_batched(DO, GG), _wgrad_batched(DF, H2)
-        gwp, gwq = _wgrad_batched(DP, A), _wgrad_batched(DQ, H1)
+        # ... written straight into the parameters' slots of the optimizer's flat gradient buffer when the same-kind weights of
+        # the stack are adjacent there (optim._kind_key): autograd then adopts the slot views as .grad, nothing is copied later
+        from .optim import grad_slots
+        def slot(k):     # only when no gradient has been accumulated into these parameters yet (the slot is overwritten)
+            ps = [params[i * PER_BLOCK + k] for i in range(nblk)]
+            return grad_slots.stacked(ps) if dev.type == "cuda" and all(p.grad is None for p in ps) else None
+        gw2, gw1 = _wgrad_batched(DO, GG, slot(9)), _wgrad_batched(DF, H2, slot(7))
+        gwp, gwq = _wgrad_batched(DP, A, slot(3)), _wgrad_batched(DQ, H1, slot(2))
         for i in range(nblk):
             grads[i * PER_BLOCK + 9], grads[i * PER_BLOCK + 7] = gw2[i], gw1[i]
             grads[i * PER_BLOCK + 3], grads[i * PER_BLOCK + 2] = gwp[i], gwq[i]

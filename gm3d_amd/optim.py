@@ -8,6 +8,9 @@ and so are its gradient slot, both Adam moments, the EMA teacher's parameters an
 One step = gm3d_adamw_ema_flat_step (3 launches) instead of ~25 multi-tensor launches and ~9 passes over 147 MB.
 """
 import ctypes
+import os
+import re
+import weakref
 
 import torch
 
@@ -20,6 +23,17 @@ def _builder_no_decay(name, p):
     return len(p.shape) == 1 or name.endswith(".bias") or "token" in name
 
 
+_BLOCK_RE = re.compile(r"^(.*\.blocks)\.(\d+)\.(.+)$")
+
+
+def _kind_key(name):
+    """Sort key that puts the same-kind weights of one block stack next to each other, in block order
+    (X.blocks.0.mlp.fc1.weight, X.blocks.1.mlp.fc1.weight, ...): the stack's batched weight-gradient GEMM then has ONE
+    contiguous (nblk, N, K) destination in the flat gradient buffer and writes it directly (fused._wgrad_batched)."""
+    m = _BLOCK_RE.match(name)
+    return (0, "", "", 0) if m is None else (1, m.group(1), m.group(3), int(m.group(2)))
+
+
 def _split_decay(model, segment_of=None, no_decay_of=None):
     no_decay_of = no_decay_of or _builder_no_decay
     decay, no_decay = [], []
@@ -27,10 +41,43 @@ def _split_decay(model, segment_of=None, no_decay_of=None):
         if not p.requires_grad:
             continue
         (no_decay if no_decay_of(name, p) else decay).append((name, p))
-    if segment_of is not None:      # stable: parameters keep their order inside a segment
-        decay.sort(key=lambda kv: segment_of(kv[0]))
-        no_decay.sort(key=lambda kv: segment_of(kv[0]))
+    seg = segment_of or (lambda n: 0)
+    # stable sorts: parameters outside the block stacks keep their order inside a segment
+    decay.sort(key=lambda kv: (seg(kv[0]),) + _kind_key(kv[0]))
+    if segment_of is not None:
+        no_decay.sort(key=lambda kv: seg(kv[0]))
     return decay, no_decay
+
+
+class _GradSlots:
+    """parameter -> its slot (a view) in a flat gradient buffer.  A backward node that produces the gradients of several
+    parameters in one tensor asks `stacked(params)` for a single destination covering their slots, when they are adjacent."""
+
+    def __init__(self):
+        self._slot = {}
+
+    def register(self, p, view):
+        self._slot[id(p)] = (weakref.ref(p), view)
+
+    def get(self, p):
+        hit = self._slot.get(id(p))
+        return hit[1] if hit is not None and hit[0]() is p else None
+
+    def stacked(self, params):
+        """params: same-shape parameters -> (len(params), *shape) view of the flat buffer covering their slots, or None."""
+        v0 = self.get(params[0])
+        if v0 is None or not ENABLE_DIRECT_WGRAD:
+            return None
+        n, step = v0.numel(), v0.numel() * v0.element_size()
+        for i, p in enumerate(params):
+            v = self.get(p)
+            if v is None or v.shape != v0.shape or v.data_ptr() != v0.data_ptr() + i * step:
+                return None
+        return torch.as_strided(v0, (len(params),) + tuple(v0.shape), (n,) + tuple(v0.stride()))
+
+
+grad_slots = _GradSlots()
+ENABLE_DIRECT_WGRAD = os.environ.get("GM3D_DIRECT_WGRAD", "1") == "1"
 
 
 class FlatAdamWEma(torch.optim.Optimizer):
@@ -71,6 +118,7 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 view.copy_(p)
                 p.data = view
                 self.gviews.append(self.G[o:o + p.numel()].view_as(p))
+                grad_slots.register(p, self.gviews[-1])
             self.PS.copy_(self.P)
         self.ema = model_ema
         self.E = self.ES = None
@@ -176,9 +224,21 @@ class FlatAdamWEma(torch.optim.Optimizer):
     def gather_grads(self):
         """Copy the gradients autograd produced (fresh tensors, no accumulate kernels) into the flat buffer with one
         multi-tensor launch; data-parallel runs call this at the end of backward so the all-reduce can work on `G`."""
-        if self._params[0].grad is not None and self._params[0].grad.data_ptr() != self.gviews[0].data_ptr():
-            grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self._params]
-            torch._foreach_copy_(self.gviews, grads)
+        if self._params[0].grad is None:            # the caller filled G itself (segmented data-parallel step)
+            self._gathered = True
+            return
+        dst, src, zero = [], [], []
+        for p, v in zip(self._params, self.gviews):
+            g = p.grad
+            if g is None:
+                zero.append(v)
+            elif g.data_ptr() != v.data_ptr():      # else: the backward node wrote this gradient into its slot already
+                dst.append(v)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        if zero:
+            torch._foreach_zero_(zero)
         self._gathered = True
 
     @torch.no_grad()

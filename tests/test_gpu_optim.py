@@ -51,3 +51,39 @@ def test_flat_optimizer_matches_torch():
     assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 5.0
     E.adjust_learning_rate(opt, 10.0, type("A", (), dict(lr=1e-3, min_lr=0.0, warmup_epochs=40, epochs=400)))
     assert abs(float(opt.lr_dev) - 2.5e-4) < 1e-9
+
+
+def test_direct_weight_gradients_land_in_flat_buffer():
+    """The block stacks' batched weight-gradient GEMMs write into the flat gradient buffer (same-kind weights adjacent in the
+    layout): after backward the parameters' .grad ARE their slots, gather_grads copies only the rest, and the gradients equal
+    those of the same step with the direct path off."""
+    import gm3d_amd.optim as O
+    from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
+    from types import SimpleNamespace
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=40)
+    x = torch.randn(8, 1024, 3, device="cuda") * 0.3
+    noise = torch.rand(8, 64, device="cuda")
+    res = {}
+    for direct in (True, False):
+        O.ENABLE_DIRECT_WGRAD = direct
+        torch.manual_seed(0)
+        model = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+        for m in model.modules():
+            if hasattr(m, "drop_prob"):
+                m.drop_prob = 0.0
+        ema = E.ModelEma(model, 0.999)
+        opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
+        E.step_forward_backward(model, ema, x.clone(), 200, args, optimizer=opt, augment=False, mask_noise=noise)
+        named = dict(model.named_parameters())
+        w = named["blocks.blocks.5.mlp.fc1.weight"]
+        slot = O.grad_slots.get(w)
+        assert (w.grad.data_ptr() == slot.data_ptr()) == direct
+        # same-kind weights of a stack are adjacent in the layout
+        w6 = O.grad_slots.get(named["blocks.blocks.6.mlp.fc1.weight"])
+        assert w6.data_ptr() == slot.data_ptr() + slot.numel() * 4
+        opt.gather_grads()
+        res[direct] = opt.G.clone()
+        opt._gathered = False
+    O.ENABLE_DIRECT_WGRAD = True
+    a, b = res[True].double(), res[False].double()
+    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
