@@ -49,7 +49,8 @@ def test_fps_large_cloud(gops, oracle_ops):
 
 
 @pytest.mark.parametrize("family", ["uniform", "gaussian", "lattice", "duplicates"])
-@pytest.mark.parametrize("N,G,k", [(1024, 64, 32), (1024, 128, 16), (1024, 256, 8), (100, 7, 64), (2048, 33, 5)])
+@pytest.mark.parametrize("N,G,k", [(1024, 64, 32), (1024, 128, 16), (1024, 256, 8), (100, 7, 64), (2048, 33, 5),
+                                   (1000, 10, 1), (777, 5, 32), (64, 3, 64)])
 def test_knn_index_exact(gops, oracle_ops, family, N, G, k):
     x = clouds.FAMILIES[family](2, N, seed=3)
     fidx = oracle_ops.furthest_point_sample(x, G)
