@@ -214,3 +214,38 @@ def test_segmented_ddp_step_through_rccl_group_of_one():
     for a, b in zip(got, ref):
         for x, y in zip(a, b):
             assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, ref)
+
+
+def test_parallel_decoders_equal_serial():
+    """The loss-prediction decoder on a second stream (default) against both decoders on one stream: same losses, same gradients
+    (the two branches share no reduction, so the results are bit-identical), eager and through a captured step."""
+    from types import SimpleNamespace
+    from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=40)
+    x = torch.randn(8, 1024, 3, device="cuda") * 0.3
+    noise = torch.rand(8, 64, device="cuda")
+    res = {}
+    was = M.PARALLEL_DECODERS
+    try:
+        for par in (True, False):
+            M.PARALLEL_DECODERS = par
+            torch.manual_seed(0)
+            model = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+            for m in model.modules():
+                if hasattr(m, "drop_prob"):
+                    m.drop_prob = 0.0
+            ema = E.ModelEma(model, 0.999)
+            opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
+            losses = []
+            for _ in range(2):
+                out = E.step_forward_backward(model, ema, x.clone(), 200, args, optimizer=opt, augment=False, mask_noise=noise)
+                opt.gather_grads()
+                losses.append((float(out["loss"]), float(out["loss_learn"])))
+                g = opt.G.clone()
+                E.step_update(model, ema, opt)
+            torch.cuda.synchronize()
+            res[par] = (losses, g, opt.P.clone())
+    finally:
+        M.PARALLEL_DECODERS = was
+    assert res[True][0] == res[False][0]
+    assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
