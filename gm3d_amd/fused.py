@@ -422,4 +422,38 @@ def run_stack(blocks, final_norm, x, pos, training):
     params = []
     for b in blocks:
         params += block_params(b)
+    ns = NOGRAD_SPLIT
+    if (ns > 1 and x.is_cuda and not training and B % ns == 0 and B // ns >= 16
+            and not (torch.is_grad_enabled() and (x.requires_grad or params[0].requires_grad))):
+        # Inference-only stack (the EMA teacher): nothing couples the clouds of a batch, and even an 8192-row chain of these kernels
+        # fills the chip about half -- the batch is cut into `ns` parts that run as parallel chains on their own streams (parallel
+        # branches of a captured graph), each kernel on 1/ns of the rows.
+        main = torch.cuda.current_stream()
+        h = B // ns
+        x, pos = x.contiguous(), pos.contiguous()
+        outs = [None] * ns
+        for j in range(1, ns):
+            side = _split_stream(x.device, j)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                outs[j] = TransformerStackFn.apply(x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h], meta, final_norm.weight, final_norm.bias,
+                                                   *params)
+            x.record_stream(side)
+            pos.record_stream(side)
+        outs[0] = TransformerStackFn.apply(x[:h], pos[:h], meta, final_norm.weight, final_norm.bias, *params)
+        for j in range(1, ns):
+            main.wait_stream(_split_stream(x.device, j))
+            outs[j].record_stream(main)
+        return torch.cat(outs, dim=0)
     return TransformerStackFn.apply(x, pos, meta, final_norm.weight, final_norm.bias, *params)
+
+
+NOGRAD_SPLIT = int(__import__("os").environ.get("GM3D_NOGRAD_SPLIT", "2"))    # parallel chains of an inference-only stack (1 = off)
+_split_streams = {}
+
+
+def _split_stream(device, j=1):
+    key = (device.type, device.index, j)
+    if key not in _split_streams:
+        _split_streams[key] = torch.cuda.Stream(device=device)
+    return _split_streams[key]

@@ -249,3 +249,25 @@ def test_parallel_decoders_equal_serial():
         M.PARALLEL_DECODERS = was
     assert res[True][0] == res[False][0]
     assert torch.equal(res[True][1], res[False][1]) and torch.equal(res[True][2], res[False][2])
+
+
+def test_inference_stack_split_equals_whole():
+    """An inference-only block stack (the EMA teacher's) run as two half-batch chains on two streams (default) against the whole
+    batch in one chain: every kernel works row by row, so the outputs are bit-identical."""
+    from gm3d_amd import fused, models_mae_learn_loss as M
+    torch.manual_seed(0)
+    model = M.mae_vit_base_patch16_dec512d8b().cuda().eval()
+    x = torch.randn(64, 1024, 3, device="cuda") * 0.3
+    mask = torch.zeros(64, 64, dtype=torch.bool, device="cuda")
+    was = fused.NOGRAD_SPLIT
+    outs = {}
+    try:
+        for ns in (2, 1):
+            fused.NOGRAD_SPLIT = ns
+            with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+                o = model(x, mask=mask, num_visible=64, need_pix_pred=False)
+            torch.cuda.synchronize()
+            outs[ns] = (o["loss_pred"].float().clone(), o["features"].float().clone())
+    finally:
+        fused.NOGRAD_SPLIT = was
+    assert torch.equal(outs[2][0], outs[1][0]) and torch.equal(outs[2][1], outs[1][1])
