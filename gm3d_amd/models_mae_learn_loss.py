@@ -450,8 +450,9 @@ class MaskedAutoencoderViT(nn.Module):
             main = torch.cuda.current_stream()
             side = _decoder_stream(x_full.device)
             side.wait_stream(main)
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side):     # the loss-prediction branch: decoder AND its head
                 loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
+                loss_pred_out = self._loss_pred_head(loss_pred_)
             x_full.record_stream(side)
             pos_full.record_stream(side)
         rebuild_points = None
@@ -465,9 +466,9 @@ class MaskedAutoencoderViT(nn.Module):
                 rebuild_points = F.linear(x_rec, c.weight.squeeze(-1), c.bias)  # B L 96
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
-            loss_pred_.record_stream(torch.cuda.current_stream())
+            loss_pred_out.record_stream(torch.cuda.current_stream())
         else:
-            loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
+            loss_pred_out = self._loss_pred_head(self.MAE_decoder_loss_pred(x_full, pos_full, N))
         return {
             "pix_pred": rebuild_points,
             "mask": mask,
@@ -475,7 +476,7 @@ class MaskedAutoencoderViT(nn.Module):
             "pos_full": pos_full,       # not in the reference dict: the segmented data-parallel backward cuts the graph here
             "cut": cut_pair,            # (x_vis, pos_full) before the cut when cut=True ("features" / "pos_full" are the leaves)
             "features": x_vis,
-            "loss_pred": self._loss_pred_head(loss_pred_),
+            "loss_pred": loss_pred_out,
             "neighborhood": neighborhood,
             "neighborhood_org": neighborhood_org,
             "center": center,
