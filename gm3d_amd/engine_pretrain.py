@@ -420,7 +420,9 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
     else:
         for p in raw.parameters():
             p.grad = None
-    total.backward()
+    from .fused import async_wgrad
+    with async_wgrad(total.device):        # the encoder stack's weight-gradient GEMMs beside the embed's backward; joined on exit
+        total.backward()
     if flat_sync:
         optimizer.gather_grads()   # one multi-tensor copy into the flat buffer the all-reduce works on
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
@@ -646,7 +648,8 @@ class SegmentedDDPStep:
         p1 = self.seg_params[1]
         outs = [t for t, gt in ((x_vis, gx), (pos_full, gp)) if gt is not None]
         gouts = [gt for gt in (gx, gp) if gt is not None]
-        g = torch.autograd.grad(outs, p1 + [tokens_d, pos_all_d], grad_outputs=gouts, allow_unused=True)
+        g = torch.autograd.grad(outs, p1 + [tokens_d, pos_all_d], grad_outputs=gouts, allow_unused=True)   # (no async_wgrad: the
+        # segment's all-reduce follows immediately, there is nothing to run the GEMMs beside)
         self._store(1, g[:len(p1)])
         self._cut3 = (g[len(p1)], g[len(p1) + 1])
 

@@ -16,6 +16,8 @@ bias / gamma / beta gradient as fused column sums.  The residual stream is fp32,
 import ctypes
 import weakref
 
+import contextlib
+
 import torch
 
 from . import _capi
@@ -236,6 +238,49 @@ def _wgrad_batched_plain(dy, x, out=None):
     return r if out is None else out.copy_(r)
 
 
+_ASYNC_WGRAD = {"stream": None, "used": False, "min_blocks": 5, "deferred": []}
+
+
+def _run_deferred(reg):
+    jobs, reg["deferred"] = reg["deferred"], []
+    cur = torch.cuda.current_stream()
+    for tensors, job in jobs:
+        for t in tensors:
+            t.record_stream(cur)
+        job()
+
+_wgrad_streams = {}
+ASYNC_WGRAD = __import__("os").environ.get("GM3D_ASYNC_WGRAD", "1") == "1"
+
+
+class async_wgrad:
+    """with async_wgrad(device): <backward>  -- weight-gradient GEMMs of the deep block stacks run on a side stream during the
+    region; on exit the current stream waits for it (so whatever follows -- gradient gather, all-reduce, optimizer -- sees them)."""
+
+    def __init__(self, device, min_blocks=5):
+        self.dev, self.min_blocks = torch.device(device), min_blocks
+
+    def __enter__(self):
+        if ASYNC_WGRAD and self.dev.type == "cuda":
+            key = (self.dev.type, self.dev.index)
+            if key not in _wgrad_streams:
+                _wgrad_streams[key] = torch.cuda.Stream(device=self.dev)
+            _ASYNC_WGRAD.update(stream=_wgrad_streams[key], used=False, min_blocks=self.min_blocks)
+        return self
+
+    def __exit__(self, *exc):
+        reg = _ASYNC_WGRAD
+        ws, used = reg["stream"], reg["used"]
+        reg.update(stream=None, used=False)
+        if reg["deferred"]:                 # no deep stack came by to take them along: run them here, in line
+            if exc[0] is None:
+                _run_deferred(reg)
+            reg["deferred"] = []
+        if ws is not None and used:
+            torch.cuda.current_stream().wait_stream(ws)
+        return False
+
+
 PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
 
 
@@ -395,8 +440,33 @@ class TransformerStackFn(torch.autograd.Function):
         def slot(k):     # only when no gradient has been accumulated into these parameters yet (the slot is overwritten)
             ps = [params[i * PER_BLOCK + k] for i in range(nblk)]
             return grad_slots.stacked(ps) if dev.type == "cuda" and all(p.grad is None for p in ps) else None
-        gw2, gw1 = _wgrad_batched(DO, GG, slot(9)), _wgrad_batched(DF, H2, slot(7))
-        gwp, gwq = _wgrad_batched(DP, A, slot(3)), _wgrad_batched(DQ, H1, slot(2))
+        # Inside an `async_wgrad` region (the engine's backward) the weight-gradient GEMMs leave the main stream:
+        #  * the 12-block encoder's four go to a side stream at once: what follows them in the backward is the mini-PointNet's
+        #    streaming (HBM-bound) passes, which leave the matrix cores idle;
+        #  * the shallow decoders' are DEFERRED to that same point (beside the encoder's latency-bound input-gradient chain, which
+        #    comes right after them, they cost 3.7 %): possible because their destinations are slots of the flat gradient buffer,
+        #    so the views handed to autograd now are filled later.  The region's exit runs whatever is still deferred and joins.
+        reg = _ASYNC_WGRAD
+        fresh = dev.type == "cuda" and all(params[i * PER_BLOCK + k].grad is None for i in range(nblk) for k in (9, 7, 3, 2))
+        ws = reg["stream"] if fresh else None
+        slots = [slot(k) for k in (9, 7, 3, 2)] if fresh else [None] * 4
+        jobs = [(DO, GG), (DF, H2), (DP, A), (DQ, H1)]
+        if ws is not None and nblk < reg["min_blocks"] and all(sl is not None for sl in slots):
+            reg["deferred"].append(((DO, GG, DF, H2, DP, A, DQ, H1),
+                                    lambda: [_wgrad_batched(dy_, x_, sl) for (dy_, x_), sl in zip(jobs, slots)]))
+            gw2, gw1, gwp, gwq = slots
+        else:
+            if ws is not None and nblk >= reg["min_blocks"]:
+                ws.wait_stream(torch.cuda.current_stream())
+                reg["used"] = True
+                for t in (DO, GG, DF, H2, DP, A, DQ, H1):
+                    t.record_stream(ws)
+            else:
+                ws = None
+            with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
+                if ws is not None:
+                    _run_deferred(reg)
+                gw2, gw1, gwp, gwq = [_wgrad_batched(dy_, x_, sl) for (dy_, x_), sl in zip(jobs, slots)]
         for i in range(nblk):
             grads[i * PER_BLOCK + 9], grads[i * PER_BLOCK + 7] = gw2[i], gw1[i]
             grads[i * PER_BLOCK + 3], grads[i * PER_BLOCK + 2] = gwp[i], gwq[i]

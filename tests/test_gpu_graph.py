@@ -271,3 +271,36 @@ def test_inference_stack_split_equals_whole():
     finally:
         fused.NOGRAD_SPLIT = was
     assert torch.equal(outs[2][0], outs[1][0]) and torch.equal(outs[2][1], outs[1][1])
+
+
+def test_async_weight_gradients_equal_inline():
+    """Inside the engine's backward the encoder's weight-gradient GEMMs run on a side stream and the decoders' are deferred to the
+    same point (fused.async_wgrad); the flat gradient buffer must be what the in-line order produces, eager and graph-captured."""
+    from types import SimpleNamespace
+    from gm3d_amd import engine_pretrain as E, fused, models_mae_learn_loss as M
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=40)
+    x = torch.randn(8, 1024, 3, device="cuda") * 0.3
+    noise = torch.rand(8, 64, device="cuda")
+    res = {}
+    was = fused.ASYNC_WGRAD
+    try:
+        for on in (True, False):
+            fused.ASYNC_WGRAD = on
+            torch.manual_seed(0)
+            model = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+            for m in model.modules():
+                if hasattr(m, "drop_prob"):
+                    m.drop_prob = 0.0
+            ema = E.ModelEma(model, 0.999)
+            opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
+            for _ in range(2):
+                E.step_forward_backward(model, ema, x.clone(), 200, args, optimizer=opt, augment=False, mask_noise=noise)
+                opt.gather_grads()
+                g = opt.G.clone()
+                E.step_update(model, ema, opt)
+            torch.cuda.synchronize()
+            assert not fused._ASYNC_WGRAD["deferred"] and fused._ASYNC_WGRAD["stream"] is None
+            res[on] = (g, opt.P.clone())
+    finally:
+        fused.ASYNC_WGRAD = was
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
