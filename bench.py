@@ -82,10 +82,10 @@ def _gemm_grid(meta):
 
 def pmc_traffic(kernel, dtype, metas=()):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_m_pmc_fetch_write_per_launch.json), corrected as
+    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_n_pmc_fetch_write_per_launch.json), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: counters are in KB, and FETCH_SIZE reports half of a coalesced stream.
     Launch-weighted mean over the kernel's shapes in the step.  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_m_pmc_fetch_write_per_launch.json")
+    path = os.path.join(ROOT, "profiles", "r01_n_pmc_fetch_write_per_launch.json")
     if not os.path.exists(path):
         return None
     if kernel.startswith("gm3d_gemm_tn_bf16"):
