@@ -13,14 +13,12 @@ Per block the forward is 4 GEMMs (hipBLASLt via torch.mm on cached bf16 weights)
 bias / gamma / beta gradient as fused column sums.  The residual stream is fp32, GEMM operands are bf16
 (throughput mode) or fp32 (parity mode: same code path, checked to 1e-5 against the reference fixtures).
 """
-import ctypes
 import weakref
 
 import contextlib
 
 import torch
 
-from . import _capi
 from ._capi import lib
 from . import gemm
 from .ops import _launch, _ptr, _stream, _DT

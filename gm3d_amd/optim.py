@@ -7,7 +7,6 @@ out for the machine: every parameter of the student is a view into one contiguou
 and so are its gradient slot, both Adam moments, the EMA teacher's parameters and the bf16 copies the GEMMs read.
 One step = gm3d_adamw_ema_flat_step (3 launches) instead of ~25 multi-tensor launches and ~9 passes over 147 MB.
 """
-import ctypes
 import os
 import re
 import weakref
