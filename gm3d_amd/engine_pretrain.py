@@ -332,7 +332,9 @@ def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
 
 
 # --------------------------------------------------------------------------- the step
-OVERLAP_EMBED = False   # measured on MI355X: running the student's embed beside the teacher's forward is 5 % SLOWER (12.2 vs 11.6 ms/step)
+# Student embed on a side stream beside the teacher's forward: 5 % slower when first measured (12.2 vs 11.6 ms/step), no gain on the
+# final step either (14,410 vs 14,426 clouds/s with the full 64-group embed on both sides) -- and it forgoes the visible-only embed.
+OVERLAP_EMBED = __import__("os").environ.get("GM3D_OVERLAP_EMBED", "0") == "1"
 _side_streams = {}
 
 
