@@ -46,8 +46,17 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
     return f_out, g_out
 
 
+_PREFER = os.environ.get("GM3D_PREFER_OWN", "")
+
+
 def prefer_own(M, N, K):
     """Shapes where the hand-written kernel beats the tuned hipBLASLt solution on MI355X (tools/gemm_kbench.py)."""
+    if _PREFER == "all":          # experiment switches (GM3D_PREFER_OWN=all|none|small): see DESIGN 3b'
+        return True
+    if _PREFER == "none":
+        return False
+    if _PREFER == "small":        # every block-stack shape up to 4096 rows
+        return M <= 4096
     return (N, K) == (384, 384) or ((N, K) == (1152, 384) and M <= 4096) or ((N, K) == (128, 256) and M >= 65536)
 
 
