@@ -667,8 +667,18 @@ __global__ __launch_bounds__(256) void head_fold_kernel(const float* __restrict_
     if ((int)blockIdx.x * 16 < C) {
         const int c = blockIdx.x * 16 + cx;
         float s = 0.f;
-        if (c < C)
-            for (int o = ry; o < nout; o += 16) s += W1[(size_t)o * C + c];
+        if (c < C) {
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;       // four independent chains: the loads of a thread overlap
+            int o = ry;
+            for (; o + 48 < nout; o += 64) {
+                s0 += W1[(size_t)o * C + c];
+                s1 += W1[(size_t)(o + 16) * C + c];
+                s2 += W1[(size_t)(o + 32) * C + c];
+                s3 += W1[(size_t)(o + 48) * C + c];
+            }
+            for (; o < nout; o += 16) s0 += W1[(size_t)o * C + c];
+            s = (s0 + s1) + (s2 + s3);
+        }
         red[threadIdx.x] = s;
         __syncthreads();
         if (ry == 0 && c < C) {
