@@ -203,10 +203,19 @@ class GradSync:
     32 MiB -> 5 collectives for the 147 MB of live fp32 gradients) beat DDP's 25 MB default + dead-parameter
     traffic.  Works on any backend (RCCL on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, model=None, model_ema=None):
+        """model / model_ema (optional): their parameters AND buffers are broadcast from rank 0 first, like the DDP constructor
+        does (the reference seeds with args.seed + rank, P/main_pretrain_multi_gpu.py:175-176: without this every rank starts
+        from different weights and averaging gradients never makes them equal again).  With only `params` given, those
+        parameters are broadcast."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
+        if self.world > 1:
+            if model is not None or model_ema is not None:
+                broadcast_state(model, model_ema, None, group=process_group)
+            else:
+                _broadcast_tensors([p.data for p in self.params], group=process_group)
         self.buckets = []   # (flat, [params])
         self._owner = {}
         cur, cur_bytes = [], 0
@@ -230,10 +239,13 @@ class GradSync:
     @classmethod
     def from_flat(cls, optimizer, bucket_bytes=32 << 20, process_group=None):
         """Buckets = contiguous chunks of FlatAdamWEma's gradient buffer (its layout, not backward order): gradients are
-        produced, all-reduced and consumed in place -- no flatten/unflatten copies."""
+        produced, all-reduced and consumed in place -- no flatten/unflatten copies.  Rank 0's parameters, optimizer state,
+        EMA teacher and buffers are broadcast first (see __init__)."""
         self = cls.__new__(cls)
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1:
+            broadcast_state(getattr(optimizer, "model", None), getattr(optimizer, "ema", None), optimizer, group=process_group)
         pairs = optimizer.flat_grad_views()
         self.params = [p for p, _ in pairs]
         self._views = pairs
@@ -272,6 +284,10 @@ class GradSync:
         else:
             for flat, _ in self.buckets:
                 flat.zero_()
+        self.reset()
+
+    def reset(self):
+        """Forget which buckets were issued: the next backward (or finish()) issues every bucket again."""
         self._pending = [len(ps) for _, ps in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._works = []
@@ -301,7 +317,53 @@ class GradSync:
             work.wait()
             if not self._avg:
                 self.buckets[b][0].div_(self.world)
-        self._works = []
+        # ready for the next step whether or not the caller goes through zero_grad() (the flat path zeroes through the
+        # optimizer, and a replayed graph calls nothing at all): every finish() issues one collective per bucket
+        self.reset()
+
+
+def _broadcast_tensors(tensors, src=0, group=None):
+    """Coalesced broadcast: one collective per dtype (pack, broadcast, unpack)."""
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for ts in by_dtype.values():
+            flat = torch.cat([t.reshape(-1) for t in ts])
+            dist.broadcast(flat, src=src, group=group)
+            off = 0
+            for t in ts:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+def broadcast_state(model=None, model_ema=None, optimizer=None, src=0, group=None):
+    """What the DDP constructor does at P/main_pretrain_multi_gpu.py:309-311, extended to everything a rank keeps: rank `src`'s
+    student parameters and buffers (integer counters included), EMA teacher and -- for FlatAdamWEma -- the flat master / moment
+    buffers and the step counter overwrite the other ranks'; the bf16 GEMM shadows are re-derived.  No-op without a group of >1."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    ts = []
+    flat = optimizer is not None and hasattr(optimizer, "flat_grad_views")
+    if flat:
+        ts += [optimizer.P, optimizer.M, optimizer.V, optimizer.step_dev]
+        if optimizer.E is not None:
+            ts.append(optimizer.E)
+    seen = {t.data_ptr() for t in ts}
+    lo, hi = (optimizer.P.data_ptr(), optimizer.P.data_ptr() + optimizer.P.numel() * 4) if flat else (0, 0)
+    elo, ehi = (optimizer.E.data_ptr(), optimizer.E.data_ptr() + optimizer.E.numel() * 4) if flat and optimizer.E is not None else (0, 0)
+    for mod in (model.module if hasattr(model, "module") else model, getattr(model_ema, "ema", model_ema)):
+        if mod is None:
+            continue
+        for t in list(mod.parameters()) + list(mod.buffers()):
+            a = t.data_ptr()
+            if a in seen or lo <= a < hi or elo <= a < ehi:       # views of the flat buffers travel with them
+                continue
+            seen.add(a)
+            ts.append(t.data)
+    _broadcast_tensors(ts, src=src, group=group)
+    if flat:
+        optimizer.sync_shadows()
 
 
 def broadcast_buffers(model, src=0, group=None):
@@ -332,19 +394,6 @@ def shard_for_rank(n_items, rank, world, epoch=0, seed=0, shuffle=True):
 
 
 # --------------------------------------------------------------------------- the step
-# Student embed on a side stream beside the teacher's forward: 5 % slower when first measured (12.2 vs 11.6 ms/step), no gain on the
-# final step either (14,410 vs 14,426 clouds/s with the full 64-group embed on both sides) -- and it forgoes the visible-only embed.
-OVERLAP_EMBED = __import__("os").environ.get("GM3D_OVERLAP_EMBED", "0") == "1"
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = str(device)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
-
 _arange_cache = {}
 
 
@@ -356,10 +405,40 @@ def _arange_ids(B, L, device):
     return _arange_cache[key]
 
 
+def backward_and_collect(total, raw, optimizer, grad_sync, accum=1, accum_first=True, accum_last=True, async_w=True):
+    """zero (first micro-batch of the window) -> backward -> gradients where the update / all-reduce expects them.
+    Shared by this engine and engine_pretrain_Classifier_SVM."""
+    flat_opt = optimizer is not None and hasattr(optimizer, "flat_grad_views")
+    flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and flat_opt
+    if grad_sync is not None and not flat_sync:
+        if accum_first:
+            grad_sync.zero_grad()
+        grad_sync.overlap = grad_sync.overlap and accum_last     # bucket collectives only on the window's summed gradients
+    elif flat_opt:
+        optimizer.zero_grad(set_to_none=True)      # every micro-batch: backward writes fresh tensors / its flat slots
+    elif accum_first:
+        if optimizer is not None:
+            optimizer.zero_grad(set_to_none=True)
+        else:
+            for p in raw.parameters():
+                p.grad = None
+    from .fused import async_wgrad
+    # the encoder stack's weight-gradient GEMMs beside the embed's backward; joined on exit
+    with (async_wgrad(total.device) if async_w else nullcontext()):
+        total.backward()
+    if flat_opt and (flat_sync or accum > 1):
+        optimizer.gather_grads()   # one multi-tensor copy into the flat buffer the all-reduce works on
+        if accum > 1:
+            optimizer.accumulate(last=accum_last)
+
+
 def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None, mask_noise=None, augment=True,
-                          aug_draws=None, optimizer=None):
+                          aug_draws=None, optimizer=None, accum_first=True, accum_last=True):
     """First half of P/engine_pretrain.py:77-197: augment -> teacher -> mask -> student -> losses -> backward.
-    Leaves the gradients in p.grad (views of GradSync's flat buckets when data-parallel)."""
+    Leaves the gradients in p.grad (views of GradSync's flat buckets when data-parallel).
+    accum_first / accum_last: position of this micro-batch in its accumulation window (args.accum_iter > 1): gradients are
+    zeroed only before the first micro-batch and summed over the window (P/engine_pretrain.py:195-212 with update_grad =
+    (it + 1) % accum_iter == 0); the data-parallel collectives run once, on the sums, in the last one."""
     raw = model.module if hasattr(model, "module") else model
     teacher = model_ema.ema
     L = raw.num_group
@@ -374,19 +453,9 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
     B = samples.shape[0]
     visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
-    overlap = OVERLAP_EMBED and samples.is_cuda
     with amp:
         with torch.no_grad():
             group = teacher.group_divider(samples)  # FPS + KNN once; shared with the student
-        tokens = pos_all = None
-        if overlap:
-            # The student's token embed and positional embed do not depend on the mask: run them on a side stream
-            # beside the teacher's forward (16 blocks of small kernels that cannot fill 256 CUs on their own).
-            main, side = torch.cuda.current_stream(), _side_stream(samples.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                tokens = raw.encoder(group[0])
-                pos_all = raw.embed_pos(group[1])
         with torch.no_grad():
             all_ids = (_arange_ids(B, L, samples.device), _arange_ids(B, 0, samples.device))
             outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False, ids=all_ids)
@@ -399,11 +468,7 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
                 mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
                                              total_epoch=args.epochs, noise=mask_noise)
             bool_masked_pos = mask.flatten(1).to(torch.bool)
-        if overlap:
-            main.wait_stream(side)
-            tokens.record_stream(main)
-            pos_all.record_stream(main)
-        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens, pos_all=pos_all, ids=ids)
+        outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, ids=ids)
         M = outs["mask_num"]
         loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"],
                                      mask_ids=ids[1] if ids is not None else None)
@@ -414,19 +479,7 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
                                                loss_outs["matrix"].detach(), relative=args.relative)
     accum = getattr(args, "accum_iter", 1)
     total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum         # P/:190,195
-    flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and optimizer is not None
-    if grad_sync is not None and not flat_sync:
-        grad_sync.zero_grad()
-    elif optimizer is not None:
-        optimizer.zero_grad(set_to_none=True)
-    else:
-        for p in raw.parameters():
-            p.grad = None
-    from .fused import async_wgrad
-    with async_wgrad(total.device):        # the encoder stack's weight-gradient GEMMs beside the embed's backward; joined on exit
-        total.backward()
-    if flat_sync:
-        optimizer.gather_grads()   # one multi-tensor copy into the flat buffer the all-reduce works on
+    backward_and_collect(total, raw, optimizer, grad_sync, accum, accum_first, accum_last)
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
             "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
             "teacher_loss_pred": outs_ema["loss_pred"]}
@@ -446,11 +499,28 @@ def step_update(model, model_ema, optimizer, clip_grad=5.0):
 
 
 def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=None, mask_noise=None,
-                  augment=True, aug_draws=None, clip_grad=5.0):
+                  augment=True, aug_draws=None, clip_grad=5.0, micro_step=None):
     """One iteration of P/engine_pretrain.py:77-212.  `samples` (B,N,3) f32 on the GPU (modified in
-    place by the augmentation, like the reference).  Returns device tensors only -- no host sync."""
+    place by the augmentation, like the reference).  Returns device tensors only -- no host sync.
+    micro_step: the iteration index `data_iter_step` when args.accum_iter > 1 -- gradients are summed over accum_iter
+    consecutive iterations and clip / AdamW / EMA / zero_grad run only when (micro_step + 1) % accum_iter == 0
+    (P/engine_pretrain.py:196-212, P/util/misc.py:256-270); the other iterations return grad_norm = None like the reference."""
+    accum = getattr(args, "accum_iter", 1)
+    if accum > 1 and micro_step is None:
+        raise ValueError("args.accum_iter = %d needs micro_step (the iteration index) to place the update" % accum)
+    first = accum == 1 or micro_step % accum == 0
+    last = accum == 1 or (micro_step + 1) % accum == 0
+    if grad_sync is not None:
+        overlap_was = grad_sync.overlap
+        raw = model.module if hasattr(model, "module") else model
+        broadcast_buffers(raw, group=grad_sync.group)          # DDP's per-forward buffer broadcast from rank 0
     out = step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=grad_sync, mask_noise=mask_noise,
-                                augment=augment, aug_draws=aug_draws, optimizer=optimizer)
+                                augment=augment, aug_draws=aug_draws, optimizer=optimizer, accum_first=first, accum_last=last)
+    if grad_sync is not None:
+        grad_sync.overlap = overlap_was
+    if not last:
+        out["grad_norm"] = None
+        return out
     if grad_sync is not None:
         grad_sync.finish()
     out["grad_norm"] = step_update(model, model_ema, optimizer, clip_grad)
@@ -458,11 +528,15 @@ def pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=N
 
 
 class GraphedPretrainStep:
-    """The whole pretrain step captured once as a hipGraph and replayed (single-GPU): the step is ~1300
-    launches, so the host cannot keep the GPU fed in eager mode.  Everything that changes between steps is
-    device state the captured kernels read: the input batch (copied into a static buffer), the learning rate
-    (optimizer built with capturable=True keeps it in a tensor), RNG offsets (graph-safe philox).  `epoch` and
-    the EMA decay are baked in at capture: re-capture (~4 step times) when the epoch changes them.
+    """The whole pretrain step captured once as a hipGraph and replayed: the step is ~700 launches, so the host cannot keep the
+    GPU fed in eager mode.  Everything that changes between steps is device state the captured kernels read: the input batch
+    (copied into a static buffer), the learning rate (a device tensor), RNG offsets (graph-safe philox).  `epoch` (the mask
+    schedule's len_loss) and the EMA decay are baked in at capture: re-capture when the epoch changes (train_one_epoch does).
+
+    Layouts: ONE graph (single GPU, accum_iter 1); TWO graphs (forward+backward | clip+AdamW+EMA) when something eager has to
+    run between them -- the bucketed all-reduce of the flat gradient buffer (`grad_sync`) and/or gradient accumulation
+    (args.accum_iter > 1: every call replays the first graph, which ends with GA += G; calls with update=True then move the sum
+    back, all-reduce it and replay the second).
 
     CAUTION (ROCm 7.2 / torch 2.10): PyTorch's multi-block reduce_kernel (sum/mean over >~64k elements, column
     sums over thousands of rows) returns stale results from the second replay on when graph-pool memory is
@@ -475,37 +549,48 @@ class GraphedPretrainStep:
         variant passes its own step_forward_backward and the frozen teacher); default: this module's.
         inject_mask_noise=True: the (B,L) ranking noise of generate_mask becomes a static input filled by the caller
         (deterministic replays for the tests); otherwise it is drawn inside the graph.
-        grad_sync: data-parallel mode -- TWO graphs (forward+backward | clip+AdamW+EMA) with the bucketed RCCL
-        all-reduce of the flat gradient buffers issued eagerly between them."""
+        warmup_iters: eager iterations on `example` before the capture -- they ARE optimizer steps; pass 0 when the caller has
+        already run eager iterations (train_one_epoch does: the first iterations of the first epoch are the warm-up)."""
         self.static_in = example.clone()
         L = (model.module if hasattr(model, "module") else model).num_group
         self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
         self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
         self.grad_sync = grad_sync
+        self.accum = getattr(args, "accum_iter", 1)
+        if self.accum > 1 and not hasattr(optimizer, "accumulate"):
+            raise NotImplementedError("captured gradient accumulation needs the flat optimizer (build_optimizer(flat=True))")
         kw = dict(augment=augment, mask_noise=self.static_noise, grad_sync=grad_sync, **(extra or {}))
+        if self.accum > 1:
+            kw.update(accum_first=True, accum_last=False)      # uniform micro-batch: GA += G (see __call__)
+            if optimizer.GA is None:                           # persistent memory, never the graph's pool
+                optimizer.GA = torch.zeros_like(optimizer.G)
         fwd_bwd = fwd_bwd or step_forward_backward
         if grad_sync is not None:
             grad_sync.overlap = False
+        two = grad_sync is not None or self.accum > 1
 
         def whole(samples):
             out = fwd_bwd(model, model_ema, samples, epoch, args, optimizer=optimizer, **kw)
+            if self.accum > 1:
+                self._collect()
             if grad_sync is not None:
                 grad_sync.finish()
             out["grad_norm"] = step_update(model, model_ema, optimizer)
             return out
 
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup_iters):
-                whole(self.static_in.clone())
-        torch.cuda.current_stream().wait_stream(side)
+        if warmup_iters:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup_iters):
+                    whole(self.static_in.clone())
+            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events; only the capturing thread's calls may abort a capture
         import os
         mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
-        if grad_sync is None:
+        if not two:
             self.graph2 = None
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = whole(self.static_in)
@@ -513,19 +598,38 @@ class GraphedPretrainStep:
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
                 self.out = fwd_bwd(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
             self.graph2 = torch.cuda.CUDAGraph()
+            if hasattr(optimizer, "mark_grads_filled"):
+                optimizer.mark_grads_filled()       # G is complete when this graph runs (gathered / collected / all-reduced)
             with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 
-    def __call__(self, samples, mask_noise=None):
+    def _collect(self):
+        """accumulated sum -> G (the buffer the all-reduce and the update work on); GA cleared for the next window."""
+        self.opt.G.copy_(self.opt.GA)
+        self.opt.GA.zero_()
+        self.opt.mark_grads_filled()
+
+    def __call__(self, samples, mask_noise=None, update=True):
+        """update=False (gradient accumulation, not the last micro-batch of its window): forward + backward only; the returned
+        grad_norm is None, like the reference's loss_scaler(update_grad=False)."""
         self.static_in.copy_(samples, non_blocking=True)
         if self.static_noise is not None:
             self.static_noise.copy_(mask_noise, non_blocking=True)
-        if self.graph2 is not None and getattr(self, "model", None) is not None:
-            broadcast_buffers(self.model.module if hasattr(self.model, "module") else self.model)   # like DDP, every forward
+        if self.grad_sync is not None and getattr(self, "model", None) is not None:
+            broadcast_buffers(self.model.module if hasattr(self.model, "module") else self.model,
+                              group=self.grad_sync.group)   # like DDP, every forward
         self.graph.replay()
-        if self.graph2 is not None:
+        if self.graph2 is None:
+            return self.out
+        if not update:
+            out = dict(self.out)
+            out["grad_norm"] = None
+            return out
+        if getattr(self, "accum", 1) > 1:
+            self._collect()
+        if self.grad_sync is not None:
             self.grad_sync.finish()
-            self.graph2.replay()
+        self.graph2.replay()
         return self.out
 
 
@@ -544,16 +648,23 @@ class SegmentedDDPStep:
     backward -- tests/test_gpu_graph.py checks it against the un-segmented step.  Needs FlatAdamWEma built with
     segment_of=ddp_segment: each segment's weight gradients are one contiguous range of the flat buffer.
     While graph 2 runs, RCCL's stream reduces segment 0 (57 MB); while graph 3 runs, segment 1 (85 MB); only segment 2's
-    ~5 MB collective is exposed."""
+    ~5 MB collective is exposed.
+    Construction broadcasts rank 0's parameters, optimizer state, EMA teacher and buffers (DDP's constructor does the same for
+    the model; the reference seeds every rank differently, P/main_pretrain_multi_gpu.py:175-176).
+    args.accum_iter > 1: the segments' gradients are summed over the window in a second flat buffer and the three collectives
+    run once, on the sums, after the window's last backward (no overlap in that mode)."""
 
     def __init__(self, model, model_ema, optimizer, args, example, epoch, warmup_iters=3, augment=True, inject_mask_noise=False,
-                 process_group=None, use_graphs=True):
+                 process_group=None, use_graphs=True, broadcast=True):
         assert getattr(optimizer, "segment_ranges", None) is not None, "build the optimizer with segment_of=ddp_segment"
         self.model, self.ema, self.opt, self.args, self.epoch = model, model_ema, optimizer, args, epoch
         self.raw = model.module if hasattr(model, "module") else model
         self.group, self.augment = process_group, augment
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.accum = getattr(args, "accum_iter", 1)
+        if broadcast:
+            broadcast_state(self.raw, model_ema, optimizer, group=process_group)
         L = self.raw.num_group
         self.static_in = example.clone()
         self.static_noise = torch.rand(example.shape[0], L, device=example.device) if inject_mask_noise else None
@@ -563,12 +674,13 @@ class SegmentedDDPStep:
         self.use_graphs = use_graphs
         self.graphs = None
         if use_graphs:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(warmup_iters):
-                    self._eager(self.static_in.clone())
-            torch.cuda.current_stream().wait_stream(side)
+            if warmup_iters:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(warmup_iters):
+                        self._eager(self.static_in.clone())
+                torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             import os
             mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
@@ -579,6 +691,7 @@ class SegmentedDDPStep:
                 with torch.cuda.graph(self.graphs[k], pool=self.graphs[0].pool(), capture_error_mode=mode):
                     phase()
             with torch.cuda.graph(self.graphs[3], pool=self.graphs[0].pool(), capture_error_mode=mode):
+                self.opt.mark_grads_filled()
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 
     # ---- the three backward segments --------------------------------------------------------------------------------
@@ -682,77 +795,177 @@ class SegmentedDDPStep:
             if not self._avg:
                 buf.div_(self.world)
 
-    def _eager(self, samples):
-        out = self._phase1(samples)
-        works = [self._reduce(0)]
-        self._phase2()
-        works.append(self._reduce(1))
-        self._phase3()
-        works.append(self._reduce(2))
-        self._wait(works)
-        self._cut1 = self._cut2 = self._cut3 = None      # eager: let the autograd graph go (captured graphs keep theirs alive)
-        out["grad_norm"] = step_update(self.model, self.ema, self.opt)
-        return out
+    def _run(self, phases, update):
+        """phases: three callables (graph replays or the eager segment functions).  accum_iter == 1: each segment's collective is
+        issued right behind its phase; accum_iter > 1: gradients join the window's sum, collectives only when `update`."""
+        if self.accum == 1:
+            works = []
+            for k in range(3):
+                phases[k]()
+                works.append(self._reduce(k))
+            self._wait(works)
+            return True
+        for k in range(3):
+            phases[k]()
+        self.opt.accumulate(last=update)
+        if update:
+            self._wait([self._reduce(k) for k in range(3)])
+        return update
 
-    def __call__(self, samples, mask_noise=None):
-        if self.graphs is None:
-            if self.static_noise is not None:
-                self.static_noise.copy_(mask_noise, non_blocking=True)
-            return self._eager(samples)
-        self.static_in.copy_(samples, non_blocking=True)
+    def _eager(self, samples, update=True):
+        res = {}
+        done = self._run([lambda: res.update(self._phase1(samples)), self._phase2, self._phase3], update)
+        self._cut1 = self._cut2 = self._cut3 = None      # eager: let the autograd graph go (captured graphs keep theirs alive)
+        if done:
+            self.opt.mark_grads_filled()
+            res["grad_norm"] = step_update(self.model, self.ema, self.opt)
+        else:
+            res["grad_norm"] = None
+        return res
+
+    def __call__(self, samples, mask_noise=None, update=True):
         if self.static_noise is not None:
             self.static_noise.copy_(mask_noise, non_blocking=True)
         broadcast_buffers(self.raw, group=self.group)      # DDP's per-forward BatchNorm-buffer broadcast from rank 0
-        works = []
-        for k in range(3):
-            self.graphs[k].replay()
-            works.append(self._reduce(k))
-        self._wait(works)
-        self.graphs[3].replay()
-        return self.out
+        if self.graphs is None:
+            return self._eager(samples, update)
+        self.static_in.copy_(samples, non_blocking=True)
+        if self._run([g.replay for g in self.graphs[:3]], update):
+            self.graphs[3].replay()
+            return self.out
+        out = dict(self.out)
+        out["grad_norm"] = None
+        return out
 
 
-def train_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler=None, log_writer=None, args=None,
-                    model_ema=None, model_teacher=None, scheduler=None, optimizer_learn_loss=None,
-                    grad_sync=None, print_freq=20):
-    """Drop-in for P/engine_pretrain.py::train_one_epoch (same positional arguments; `loss_scaler` is
-    accepted for signature compatibility -- bf16/fp32 need no GradScaler).  The data loader yields
-    (B,N,3) float tensors.  Returns the epoch's averaged stats like the reference (:268-271)."""
-    assert args.learning_loss and model_ema is not None, "the north-star path trains with the EMA teacher"
-    model.train(True)
-    model_ema.decay = ema_decay_for_epoch(epoch)
+# --------------------------------------------------------------------------- the epoch loop
+_warm = {}      # id(model) -> eager iterations run so far (lazy initialisation, library workspaces, code objects)
+EAGER_WARMUP_ITERS = 3
+
+
+def make_captured_step(model, model_ema, optimizer, args, example, epoch, grad_sync=None, fwd_bwd=None, extra=None):
+    """The captured form of one iteration of this epoch for the process's situation: SegmentedDDPStep when a process group of
+    more than one rank is alive and the flat optimizer is laid out by backward segment, else GraphedPretrainStep (two graphs
+    around the bucketed all-reduce when data-parallel, one graph on a single GPU).  No warm-up iterations: the caller has run
+    eager ones."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1 and fwd_bwd is None and getattr(optimizer, "segment_ranges", None) is not None:
+        return SegmentedDDPStep(model, model_ema, optimizer, args, example, epoch, warmup_iters=0,
+                                process_group=getattr(grad_sync, "group", None), broadcast=False)
+    return GraphedPretrainStep(model, model_ema, optimizer, args, example, epoch, warmup_iters=0, grad_sync=grad_sync,
+                               fwd_bwd=fwd_bwd, extra=extra)
+
+
+def run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, log_writer=None, print_freq=20,
+              loss_scale=(13.889, 1.0), model_key=None, use_graph=True):
+    """The loop of P/engine_pretrain.py:68-257 around one engine's iteration (shared with engine_pretrain_Classifier_SVM).
+    eager_step(samples, it) -> out dict; capture(example) -> a callable step(samples, update=) or None.
+    Iterations run as hipGraph replays (what bench.py measures) once EAGER_WARMUP_ITERS eager iterations have run in this
+    process -- the first iterations of the first epoch; a batch of another shape (a smaller last batch) runs eagerly.
+    Learning rate: per iteration, set only at the start of an accumulation window (P/:72-73)."""
     n_iter = len(data_loader)
-    sums = None
+    accum = getattr(args, "accum_iter", 1)
+    sums, n_upd, gsum, lr = None, 0, None, 0.0
     bad = torch.zeros((), dtype=torch.bool, device=device)
-    t0 = time.time()
-    seen = 0
+    t0, seen = time.time(), 0
+    graphed, t_replay, seen_replay, n_replay, t_capture = None, 0.0, 0, 0, 0.0
+    rank0 = not dist.is_initialized() or dist.get_rank() == 0
     for it, points in enumerate(data_loader):
-        lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args)
+        if it % accum == 0:
+            lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args)
         samples = points.to(device, non_blocking=True)
-        out = pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=grad_sync)
-        vec = torch.stack([out["loss"] + out["loss_learn"], out["loss_learn"], out["loss_mse"] * 13.889,
-                           out["loss_chfr"], out["grad_norm"].float()])
+        last = (it + 1) % accum == 0
+        if (use_graph and graphed is None and it % accum == 0 and _warm.get(model_key, 0) >= EAGER_WARMUP_ITERS * accum
+                and samples.is_cuda):
+            tc = time.time()
+            graphed = capture(samples)
+            torch.cuda.synchronize()
+            t_capture = time.time() - tc
+            use_graph = graphed is not None
+            tr0 = time.time()
+        if graphed is not None and samples.shape == graphed.static_in.shape:
+            out = graphed(samples, update=last)
+            seen_replay += samples.shape[0]
+            n_replay += 1
+        else:
+            out = eager_step(samples, it)
+            _warm[model_key] = _warm.get(model_key, 0) + 1
+        vec = torch.stack([out["loss"] + out["loss_learn"], out["loss_learn"], out["loss_mse"] * loss_scale[0],
+                           out["loss_chfr"] * loss_scale[1]])
         bad |= ~torch.isfinite(vec).all()
         sums = vec if sums is None else sums + vec
+        if out["grad_norm"] is not None:        # the reference's grad_norm is None on accumulation-only iterations
+            g = out["grad_norm"].float().reshape(())
+            bad |= ~torch.isfinite(g)
+            gsum = g.clone() if gsum is None else gsum + g
+            n_upd += 1
         seen += samples.shape[0]
         if (it + 1) % print_freq == 0 or it + 1 == n_iter:
             if bool(bad):  # the reference exits on a non-finite loss (:173-175,185-187); one sync per print_freq
                 raise FloatingPointError("non-finite loss in epoch %d near iteration %d" % (epoch, it))
-            cur = (sums / (it + 1)).tolist()
+            cur = (sums / (it + 1)).tolist() + [float(gsum) / max(n_upd, 1) if gsum is not None else 0.0]
             if log_writer is not None:
                 step = n_iter * epoch + it
                 for name, v in zip(("train_loss", "train_loss_learn", "train_loss_MSE", "train_loss_Chfr", "grad_norm"), cur):
                     log_writer.add_scalar(name, v, step)
                 log_writer.add_scalar("lr", lr, step)
-            if not dist.is_initialized() or dist.get_rank() == 0:
-                print("Epoch: [%d]  [%d/%d]  lr %.6f  loss %.4f  loss_learn %.4f  loss_chfr %.4f  grad_norm %.3f  "
-                      "%.0f clouds/s" % (epoch, it + 1, n_iter, lr, cur[0], cur[1], cur[3], cur[4],
+            if rank0:
+                print("Epoch: [%d]  [%d/%d]  lr %.6f  loss %.4f  loss_learn %.4f  loss_mse %.4f  loss_chfr %.4f  grad_norm %.3f  "
+                      "%.0f clouds/s" % (epoch, it + 1, n_iter, lr, cur[0], cur[1], cur[2], cur[3], cur[4],
                                          seen / (time.time() - t0)))
         if it + 1 >= n_iter:
             break
-    stats = sums / max(n_iter, 1)
+    if device.type == "cuda":
+        torch.cuda.synchronize()
+    t_end = time.time()
+    if graphed is not None:
+        t_replay = t_end - tr0
+    stats = torch.cat([sums / max(n_iter, 1), (gsum / max(n_upd, 1) if gsum is not None else torch.zeros((), device=device)).reshape(1)])
     if dist.is_initialized() and dist.get_world_size() > 1:  # one fused metric all-reduce per epoch
         dist.all_reduce(stats)
         stats /= dist.get_world_size()
     s = stats.tolist()
-    return {"loss": s[0], "loss_learn": s[1], "loss_mse": s[2], "loss_chfr": s[3], "grad_norm": s[4], "lr": lr}
+    return {"loss": s[0], "loss_learn": s[1], "loss_mse": s[2], "loss_chfr": s[3], "grad_norm": s[4], "lr": lr,
+            # execution record (not in the reference's dict): clouds/s of this rank over the whole epoch and over the replayed part
+            "clouds_per_s": seen / max(t_end - t0, 1e-9),
+            "replay_clouds_per_s": seen_replay / t_replay if t_replay > 0 else 0.0,
+            "replayed_iters": n_replay, "capture_s": t_capture}
+
+
+def train_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler=None, log_writer=None, args=None,
+                    model_ema=None, model_teacher=None, scheduler=None, optimizer_learn_loss=None,
+                    grad_sync=None, print_freq=20, use_graph=None):
+    """Drop-in for P/engine_pretrain.py::train_one_epoch (same positional arguments; `loss_scaler` is
+    accepted for signature compatibility -- bf16/fp32 need no GradScaler).  The data loader yields this rank's
+    (B,N,3) float batches (shard_for_rank gives the DistributedSampler partition the reference omits).  Returns the epoch's
+    averaged stats like the reference (:268-271).
+
+    Execution: with the flat optimizer (build_optimizer(flat=True, model_ema=...)) on a GPU the iterations are hipGraph
+    replays -- the configuration bench.py measures: one graph on a single GPU; with a process group of >1 ranks the four-graph
+    SegmentedDDPStep (optimizer built with segment_of=ddp_segment) or two graphs around GradSync.from_flat's all-reduce (created
+    here when the caller passed none).  The capture happens once per epoch (the epoch's mask schedule and EMA decay are baked
+    in), after the process's first EAGER_WARMUP_ITERS iterations, which run eagerly.  use_graph=False (or a torch optimizer, or
+    GM3D_EAGER_EPOCH=1) keeps every iteration eager.  args.accum_iter follows P/:72-73,196-212: lr set, and clip / AdamW / EMA /
+    zero_grad run, once per window."""
+    import os
+    assert args.learning_loss and model_ema is not None, "the north-star path trains with the EMA teacher"
+    model.train(True)
+    model_ema.decay = ema_decay_for_epoch(epoch)
+    device = torch.device(device)
+    flat = hasattr(optimizer, "flat_grad_views")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1 and grad_sync is None and flat:
+        grad_sync = getattr(optimizer, "_grad_sync", None)
+        if grad_sync is None:       # the all-reduce works in place on the optimizer's flat gradient buffer; also broadcasts rank 0's state
+            grad_sync = optimizer._grad_sync = GradSync.from_flat(optimizer, bucket_bytes=256 << 20)
+    if use_graph is None:
+        use_graph = flat and device.type == "cuda" and os.environ.get("GM3D_EAGER_EPOCH") != "1"
+
+    def eager_step(samples, it):
+        return pretrain_step(model, model_ema, optimizer, samples, epoch, args, grad_sync=grad_sync, micro_step=it)
+
+    def capture(example):
+        return make_captured_step(model, model_ema, optimizer, args, example, epoch, grad_sync=grad_sync)
+
+    return run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, log_writer=log_writer,
+                     print_freq=print_freq, model_key=id(model), use_graph=use_graph)

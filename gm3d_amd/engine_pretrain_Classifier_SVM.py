@@ -11,7 +11,6 @@
 FPS + KNN run once and are shared by the three networks (identical `samples`).  The online-classifier branch
 (`classification=True`, off by default in the reference) is not part of this path.
 """
-import time
 from contextlib import nullcontext
 
 import torch
@@ -31,7 +30,7 @@ def loss_weights(epoch, args):
 
 
 def step_forward_backward(model, model_ema, samples, epoch, args, model_teacher=None, grad_sync=None, mask_noise=None,
-                          augment=True, aug_draws=None, optimizer=None):
+                          augment=True, aug_draws=None, optimizer=None, accum_first=True, accum_last=True):
     assert model_teacher is not None, "the published run needs the frozen Point-MAE teacher (--learn_feature_loss dino)"
     raw = model.module if hasattr(model, "module") else model
     teacher = model_ema.ema
@@ -73,27 +72,33 @@ def step_forward_backward(model, model_ema, samples, epoch, args, model_teacher=
         loss = w_mse * loss_mse + w_chfr * loss_chfr
         loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos, loss_outs["matrix"].detach(),
                                                relative=args.relative)
-    total = (loss + loss_learn) / getattr(args, "accum_iter", 1)
-    flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and optimizer is not None
-    if grad_sync is not None and not flat_sync:
-        grad_sync.zero_grad()
-    elif optimizer is not None:
-        optimizer.zero_grad(set_to_none=True)
-    else:
-        for p in raw.parameters():
-            p.grad = None
-    total.backward()
-    if flat_sync:
-        optimizer.gather_grads()
+    accum = getattr(args, "accum_iter", 1)
+    total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum
+    E.backward_and_collect(total, raw, optimizer, grad_sync, accum, accum_first, accum_last, async_w=False)
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
             "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
             "teacher_loss_pred": outs_ema["loss_pred"]}
 
 
 def pretrain_step(model, model_ema, model_teacher, optimizer, samples, epoch, args, grad_sync=None, mask_noise=None,
-                  augment=True, aug_draws=None, clip_grad=5.0):
+                  augment=True, aug_draws=None, clip_grad=5.0, micro_step=None):
+    """One iteration; args.accum_iter > 1 needs micro_step (see engine_pretrain.pretrain_step: same window rule, P/:300-316)."""
+    accum = getattr(args, "accum_iter", 1)
+    if accum > 1 and micro_step is None:
+        raise ValueError("args.accum_iter = %d needs micro_step (the iteration index) to place the update" % accum)
+    first = accum == 1 or micro_step % accum == 0
+    last = accum == 1 or (micro_step + 1) % accum == 0
+    if grad_sync is not None:
+        overlap_was = grad_sync.overlap
+        E.broadcast_buffers(model.module if hasattr(model, "module") else model, group=grad_sync.group)
     out = step_forward_backward(model, model_ema, samples, epoch, args, model_teacher=model_teacher, grad_sync=grad_sync,
-                                mask_noise=mask_noise, augment=augment, aug_draws=aug_draws, optimizer=optimizer)
+                                mask_noise=mask_noise, augment=augment, aug_draws=aug_draws, optimizer=optimizer,
+                                accum_first=first, accum_last=last)
+    if grad_sync is not None:
+        grad_sync.overlap = overlap_was
+    if not last:
+        out["grad_norm"] = None
+        return out
     if grad_sync is not None:
         grad_sync.finish()
     out["grad_norm"] = step_update(model, model_ema, optimizer, clip_grad)
@@ -109,8 +114,9 @@ def graphed_step(model, model_ema, model_teacher, optimizer, args, example, epoc
 def train_one_epoch(model, classifier, data_loader, data_loader_classifier, criterion_cls, optimizer, optimizer_cls, device,
                     epoch, loss_scaler=None, log_writer=None, args=None, model_ema=None, model_teacher=None, scheduler=None,
                     optimizer_learn_loss=None, after_200_epoch=None, classification=None, loss_multiply_by=None,
-                    after_epoch=None, shared_learnable_tokens=None, grad_sync=None, print_freq=20):
-    """Reference signature (P/:40-45).  Averaged stats like P/:330-332."""
+                    after_epoch=None, shared_learnable_tokens=None, grad_sync=None, print_freq=20, use_graph=None):
+    """Reference signature (P/:40-45).  Averaged stats like P/:330-332.  Iterations run as hipGraph replays under the same
+    conditions as engine_pretrain.train_one_epoch (flat optimizer, GPU), captured once per epoch."""
     if classification:
         raise NotImplementedError("the online classifier branch (classification=True) is outside this path")
     assert args.learning_loss and model_ema is not None and model_teacher is not None
@@ -118,40 +124,26 @@ def train_one_epoch(model, classifier, data_loader, data_loader_classifier, crit
                  ("shared_learnable_tokens", shared_learnable_tokens)):
         if v is not None:
             setattr(args, k, v)
+    import os
     model.train(True)
     model_teacher.eval()
     model_ema.decay = ema_decay_for_epoch(epoch)          # P/:61-66, same schedule as the north-star engine
-    n_iter = len(data_loader)
-    sums, lr = None, 0.0
-    bad = torch.zeros((), dtype=torch.bool, device=device)
-    t0, seen = time.time(), 0
-    w_mse, w_chfr = loss_weights(epoch, args)
-    for it, points in enumerate(data_loader):
-        lr = adjust_learning_rate(optimizer, it / n_iter + epoch, args)
-        samples = points.to(device, non_blocking=True)
-        out = pretrain_step(model, model_ema, model_teacher, optimizer, samples, epoch, args, grad_sync=grad_sync)
-        vec = torch.stack([out["loss"] + out["loss_learn"], out["loss_learn"], out["loss_mse"] * w_mse,
-                           out["loss_chfr"] * w_chfr, out["grad_norm"].float()])
-        bad |= ~torch.isfinite(vec).all()
-        sums = vec if sums is None else sums + vec
-        seen += samples.shape[0]
-        if (it + 1) % print_freq == 0 or it + 1 == n_iter:
-            if bool(bad):
-                raise FloatingPointError("non-finite loss in epoch %d near iteration %d" % (epoch, it))
-            cur = (sums / (it + 1)).tolist()
-            if log_writer is not None:
-                step = n_iter * epoch + it
-                for name, v in zip(("train_loss", "train_loss_learn", "train_loss_MSE", "train_loss_Chfr", "grad_norm"), cur):
-                    log_writer.add_scalar(name, v, step)
-                log_writer.add_scalar("lr", lr, step)
-            if not dist.is_initialized() or dist.get_rank() == 0:
-                print("Epoch: [%d]  [%d/%d]  lr %.6f  loss %.4f  loss_learn %.4f  mse %.4f  chfr %.4f  %.0f clouds/s"
-                      % (epoch, it + 1, n_iter, lr, cur[0], cur[1], cur[2], cur[3], seen / (time.time() - t0)))
-        if it + 1 >= n_iter:
-            break
-    stats = sums / max(n_iter, 1)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(stats)
-        stats /= dist.get_world_size()
-    s = stats.tolist()
-    return {"loss": s[0], "loss_learn": s[1], "loss_mse": s[2], "loss_chfr": s[3], "grad_norm": s[4], "lr": lr}
+    device = torch.device(device)
+    flat = hasattr(optimizer, "flat_grad_views")
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    if world > 1 and grad_sync is None and flat:
+        grad_sync = getattr(optimizer, "_grad_sync", None)
+        if grad_sync is None:
+            grad_sync = optimizer._grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=256 << 20)
+    if use_graph is None:
+        use_graph = flat and device.type == "cuda" and os.environ.get("GM3D_EAGER_EPOCH") != "1"
+
+    def eager_step(samples, it):
+        return pretrain_step(model, model_ema, model_teacher, optimizer, samples, epoch, args, grad_sync=grad_sync, micro_step=it)
+
+    def capture(example):
+        return E.make_captured_step(model, model_ema, optimizer, args, example, epoch, grad_sync=grad_sync,
+                                    fwd_bwd=step_forward_backward, extra={"model_teacher": model_teacher})
+
+    return E.run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, log_writer=log_writer,
+                       print_freq=print_freq, loss_scale=loss_weights(epoch, args), model_key=id(model), use_graph=use_graph)

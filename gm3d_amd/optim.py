@@ -120,6 +120,8 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 grad_slots.register(p, self.gviews[-1])
             self.PS.copy_(self.P)
         self.ema = model_ema
+        self.model = model          # kept for the data-parallel start-up broadcast (engine_pretrain.broadcast_state)
+        self.GA = None              # gradient-accumulation buffer (accum_iter > 1), allocated on first use
         self.E = self.ES = None
         if model_ema is not None:
             tparams = dict(model_ema.ema.named_parameters())
@@ -180,6 +182,7 @@ class FlatAdamWEma(torch.optim.Optimizer):
         return list(zip(self._params, self.gviews))
 
     def zero_grad(self, set_to_none=True):
+        self._gathered = False          # whatever backward produces next has to be gathered again
         if set_to_none:
             for p in self._params:
                 p.grad = None
@@ -188,20 +191,40 @@ class FlatAdamWEma(torch.optim.Optimizer):
             for p, g in zip(self._params, self.gviews):
                 p.grad = g
 
+    def state_dict(self):
+        """torch.optim.Optimizer.state_dict() plus `param_names`: the parameter name of every index, in this optimizer's own
+        order (decayed parameters first, block-stack weights grouped by kind).  That order is NOT the reference AdamW's (two
+        groups [no_decay, decay] in named_parameters order over all 470 tensors incl. the dead ones, P/tools/builder.py:40-56),
+        so the 'optimizer' entry of a checkpoint is interchangeable between gm3d_amd runs only; model and EMA tensors are
+        interchangeable with the reference (checkpoint.py)."""
+        sd = super().state_dict()
+        sd["param_names"] = [n for n, _ in self._named]
+        return sd
+
     @torch.no_grad()
     def load_state_dict(self, state_dict):
-        """Restore from `state_dict()` of a FlatAdamWEma (or of an AdamW over the same parameter order): the moments are
-        copied INTO the flat buffers (torch's default would re-point the state at fresh tensors and break the layout)."""
+        """Restore from `state_dict()` of a FlatAdamWEma over the same model: the moments are copied INTO the flat buffers
+        (torch's default would re-point the state at fresh tensors and break the layout).  Entries are matched by parameter
+        NAME when the file carries `param_names` (any layout order), by position otherwise; shapes are verified either way."""
         ids = [i for g in state_dict["param_groups"] for i in g["params"]]
         if len(ids) != len(self._params):
             raise ValueError("optimizer state has %d parameters, this model %d" % (len(ids), len(self._params)))
+        names = state_dict.get("param_names")
+        if names is not None:
+            if sorted(names) != sorted(n for n, _ in self._named):
+                raise ValueError("optimizer state was written for a different set of parameters")
+            by_name = dict(zip(names, ids))
+            ids = [by_name[n] for n, _ in self._named]
         state = state_dict["state"]
         step = 0.0
-        for pid, p, o in zip(ids, self._params, self._offs):
+        for pid, p, o, (name, _) in zip(ids, self._params, self._offs, self._named):
             st = state.get(pid, state.get(str(pid)))
             if st is None:
                 continue
             n = p.numel()
+            if tuple(st["exp_avg"].shape) != tuple(p.shape) or tuple(st["exp_avg_sq"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state of %s has shape %s, the parameter %s"
+                                 % (name, tuple(st["exp_avg"].shape), tuple(p.shape)))
             self.M[o:o + n].copy_(st["exp_avg"].reshape(-1))
             self.V[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
             step = max(step, float(st["step"]))
@@ -219,12 +242,31 @@ class FlatAdamWEma(torch.optim.Optimizer):
         if self.E is not None:
             self.ES.copy_(self.E)
 
+    def mark_grads_filled(self):
+        """The caller wrote every gradient into `G` itself (the segmented data-parallel step stores each backward segment into
+        its range): the next step() must not gather from p.grad."""
+        self._gathered = True
+
+    @torch.no_grad()
+    def accumulate(self, last):
+        """Gradient accumulation over micro-batches (accum_iter > 1; P/engine_pretrain.py:195-212 accumulates into p.grad): call
+        after gather_grads() of every micro-batch.  G holds this micro-batch's gradients (backward nodes overwrite their slots),
+        GA the running sum: not last -> GA += G; last -> G += GA, GA = 0, so that clip / all-reduce / AdamW see the sum."""
+        if self.GA is None:
+            self.GA = torch.zeros_like(self.G)
+        if last:
+            self.G.add_(self.GA)
+            self.GA.zero_()
+        else:
+            self.GA.add_(self.G)
+            self._gathered = False      # the next micro-batch gathers again
+
     @torch.no_grad()
     def gather_grads(self):
         """Copy the gradients autograd produced (fresh tensors, no accumulate kernels) into the flat buffer with one
-        multi-tensor launch; data-parallel runs call this at the end of backward so the all-reduce can work on `G`."""
-        if self._params[0].grad is None:            # the caller filled G itself (segmented data-parallel step)
-            self._gathered = True
+        multi-tensor launch; data-parallel runs call this at the end of backward so the all-reduce can work on `G`.
+        Slots of parameters that received no gradient this iteration are zeroed (never left at the previous step's values)."""
+        if getattr(self, "_gathered", False):       # mark_grads_filled(): G is complete already
             return
         dst, src, zero = [], [], []
         for p, v in zip(self._params, self.gviews):

@@ -304,3 +304,39 @@ def test_async_weight_gradients_equal_inline():
     finally:
         fused.ASYNC_WGRAD = was
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
+def test_flat_gradsync_all_reduces_on_every_step(monkeypatch):
+    """pretrain_step and the two-graph GraphedPretrainStep with GradSync.from_flat must issue one collective per
+    bucket on EVERY step (world forced to 2, dist.all_reduce replaced by a counter)."""
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import models_mae_learn_loss as M
+    from tests import clouds
+    B = 4
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
+    x = clouds.uniform(B, 1024, 5).cuda()
+    torch.manual_seed(0)
+    m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+    ema = E.ModelEma(m, 0.999)
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema)
+    sync = E.GradSync.from_flat(opt, bucket_bytes=32 << 20)
+    nb = len(sync.buckets)
+    calls = []
+
+    class Work:
+        def wait(self):
+            pass
+
+    monkeypatch.setattr(E.dist, "all_reduce", lambda t, **k: (calls.append(t.numel()), Work())[1])
+    sync.world = 2
+    for step in range(3):
+        E.pretrain_step(m, ema, opt, x.clone(), 200, args, grad_sync=sync)
+        assert len(calls) == nb * (step + 1), (step, len(calls))
+    g = E.GraphedPretrainStep(m, ema, opt, args, x, 200, warmup_iters=0, grad_sync=sync)
+    assert g.graph2 is not None
+    del calls[:]
+    for step in range(3):
+        g(x)
+        assert len(calls) == nb * (step + 1), (step, len(calls))
+    torch.cuda.synchronize()
+    assert sum(calls[:nb]) == opt.G.numel()
