@@ -7,6 +7,11 @@ Resume follows util/misc.py:317-342 (load_model); fine-tune initialisation follo
 (key 'ema_state_dict' for --teacher, else 'state_dict' / 'model'; 'module.' and 'MAE_encoder.' prefixes dropped;
 strict=False).
 
+The 'optimizer' entry: torch.optim.AdamW's state_dict when the run uses it; with FlatAdamWEma (the measured configuration) it is
+that optimizer's own layout plus `param_names` -- restored by parameter name into any FlatAdamWEma over the same model, but NOT
+loadable by the reference's optimizer.load_state_dict (util/misc.py:335: two groups [no_decay, decay] in named_parameters order
+over all 470 tensors, dead ones included).  Model and EMA tensors are interchangeable with the reference in both directions.
+
 Files hold tensors, numbers, strings, lists and dicts only, so they load with torch.load(weights_only=True) -- here and
 in the reference (whose torch.load default accepts them as well).  The reference model additionally carries ~230 dead
 image-MAE entries (patch_embed.*, decoder_*, ...: SURVEY.md 0.7); `reference_keys=` lets a caller add them (zeros) so

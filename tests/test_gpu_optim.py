@@ -87,3 +87,49 @@ def test_direct_weight_gradients_land_in_flat_buffer():
     O.ENABLE_DIRECT_WGRAD = True
     a, b = res[True].double(), res[False].double()
     assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+
+def test_state_dict_round_trip_by_parameter_name_and_stale_gradient_guard():
+    """(1) the optimizer entry of a checkpoint carries parameter names; a FlatAdamWEma with ANOTHER layout (segment
+    order) restores every moment to the right parameter, a mismatching file is refused; (2) step() after zero_grad() with no
+    backward, or with a parameter that received no gradient, uses zeros -- never the previous step's gradients."""
+    from gm3d_amd import engine_pretrain as E
+    torch.manual_seed(0)
+
+    def net():
+        torch.manual_seed(1)
+        return torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.LayerNorm(16), torch.nn.Linear(16, 16)).cuda()
+
+    a = net()
+    oa = E.build_optimizer(a, lr=1e-3, flat=True)
+    x = torch.randn(8, 16, device="cuda")
+    for _ in range(2):
+        oa.zero_grad()
+        a(x).pow(2).mean().backward()
+        oa.step()
+    sd = oa.state_dict()
+    assert sd["param_names"] == [n for n, _ in oa._named]
+    b = net()
+    ob = E.build_optimizer(b, lr=1e-3, flat=True, segment_of=lambda n: 0 if n.startswith("2.") else 1)   # "2.*" first: another order
+    assert [n for n, _ in ob._named] != [n for n, _ in oa._named]
+    ob.load_state_dict(sd)
+    ma = {n: oa.state[p]["exp_avg"] for n, p in oa._named}
+    for n, p in ob._named:
+        assert torch.equal(ob.state[p]["exp_avg"], ma[n]), n
+    assert float(ob.step_dev) == 2.0
+    bad = dict(sd, param_names=["x." + n for n in sd["param_names"]])
+    with pytest.raises(ValueError):
+        ob.load_state_dict(bad)
+    # (2) a step without gradients moves parameters only by weight decay (Adam's moments decay towards zero)
+    oa.zero_grad()
+    a(x).pow(2).mean().backward()
+    oa.step()
+    assert float(oa.G.abs().max()) > 0
+    oa.zero_grad()
+    oa.step()                       # no backward in between
+    assert float(oa.G.abs().max()) == 0.0
+    oa.zero_grad()
+    a[0](x).pow(2).mean().backward()        # only the first layer receives a gradient
+    oa.step()
+    slot = {id(p): v for p, v in oa.flat_grad_views()}
+    assert float(slot[id(a[2].weight)].abs().max()) == 0.0 and float(slot[id(a[0].weight)].abs().max()) > 0
