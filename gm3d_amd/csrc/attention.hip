@@ -92,41 +92,117 @@ __device__ __forceinline__ void stage_f32(float* dst /*[rows*64]*/, const float*
     }
 }
 
-// ===================================================================== forward, bf16
-template <int MT>
-__global__ __launch_bounds__(64 * MT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                float* __restrict__ lse, int T, int H, float scale) {
-    __shared__ __attribute__((aligned(16))) bf16_t Vs[32 * MT * VLD];
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int lane = threadIdx.x & 63, qb = threadIdx.x >> 6;  // wave = 32-query block
+// ===================================================================== LDS images (bf16 kernels)
+// A head's (T,64) bf16 slice lives in LDS as a swizzled [rows][64] image with 128-byte rows and NO padding: the 16-byte chunk
+// ch (0..7) of row `row` sits at byte 128*row + 16*(ch ^ f(row)), f = the bit-reversed (row >> 1) & 7.  One image serves both
+// kinds of MFMA operand read conflict-free (bank rule of ds_read_b128 / ds_read_b64_tr_b16: 64 banks, MI355X_MICROARCH.md LDS):
+//   row read   (ds_read_b128):        a 16-lane group reads one chunk of 16 different rows -> f spreads them over all 16 slots;
+//   transposed (ds_read_b64_tr_b16):  a 32-lane half reads 4 consecutive rows x 32 columns -> (row & 1, f bit 2) picks a
+//                                     different 64-byte quarter of the bank row for each of the four rows.
+__device__ __forceinline__ int img_off(int row, int ch) {
+    const int f = (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+    return row * 128 + ((ch ^ f) << 4);
+}
+typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+// operand fragment read along a row: 8 consecutive d (chunk ch) of row `row`
+__device__ __forceinline__ bf16x8 img_row(const unsigned char* img, int row, int ch) {
+    return *reinterpret_cast<const bf16x8*>(img + img_off(row, ch));
+}
+// operand fragment read down the columns: this lane's column is colblk + (lane & 15) (+16 for the upper 16-lane group of each
+// half, folded into colblk by the caller); it receives M[row0 + 0..3][col] -- the hardware transpose of a 4 x 16 block whose
+// row q / columns 4p..4p+3 address is supplied by lane 4q + p of the 16-lane group.  EXEC must be all ones (it is: no caller
+// sits inside a lane-divergent branch).
+__device__ __forceinline__ bf16x4 img_tr(const unsigned char* img, int row0, int colblk, int lane) {
+    const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3;
+    const int col = colblk + 4 * p;
+    const int addr = img_off(row0 + q, col >> 3) + ((col >> 2) & 1) * 8;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)(img + addr));
+}
+// A[i = column][k] fragment for the accumulator-as-operand k order (permk): rows k0 + 16 s + 4 hh + {0..3, 8..11}
+__device__ __forceinline__ bf16x8 img_tr8(const unsigned char* img, int k0, int s, int hh, int colblk, int lane) {
+    const bf16x4 lo = img_tr(img, k0 + 16 * s + 4 * hh, colblk, lane);
+    const bf16x4 hi = img_tr(img, k0 + 16 * s + 8 + 4 * hh, colblk, lane);
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    return v;
+}
+// Transposed result tile X^T[d (registers)][row (lane)] (two 32-d halves) -> the image rows of this wave's 32 rows, then out
+// to global memory as whole 128-byte rows in 16-byte pieces (8 lanes per row).  `img` rows row0..row0+31 must be owned by the
+// calling wave; the caller has made sure nobody still reads them.
+__device__ __forceinline__ void store_tile_t(unsigned char* img, int row0, const f32x16& x0, const f32x16& x1, int lane, bf16_t* g,
+                                             size_t row_stride, int T) {
     const int r = lane & 31, hh = lane >> 5;
-    const size_t rs = (size_t)3 * H * HD;
-    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
-    const bf16_t* Kg = Qg + (size_t)H * HD;
-    const bf16_t* Vg = Kg + (size_t)H * HD;
-    const int NK = (T + 31) >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x16& x = dt ? x1 : x0;
+            bf16x4 pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)x[4 * g4 + e];          // d = 32 dt + 8 g4 + 4 hh + e
+            *reinterpret_cast<bf16x4*>(img + img_off(row0 + r, 4 * dt + g4) + 8 * hh) = pk;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (lane >> 3) + 8 * i, ch = lane & 7;
+        if (row0 + row < T)
+            *reinterpret_cast<uint4*>(g + (size_t)(row0 + row) * row_stride + ch * 8) =
+                *reinterpret_cast<const uint4*>(img + img_off(row0 + row, ch));
+    }
+}
 
-    stage_bf16(Vs, Vg, rs, T, 32 * MT);
+// ===================================================================== forward, bf16
+// NT = number of 32-row tiles = waves (T <= 32 NT).  LDS: Q, K, V images.  Every 16-byte chunk of the head's q|k|v slab is
+// requested up front with coalesced loads (8 lanes per 128-byte row piece), 12 per thread.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWS = 32 * NT, IMG = ROWS * 128;
+    unsigned char* Qi = smem;
+    unsigned char* Ki = Qi + IMG;
+    unsigned char* Vi = Ki + IMG;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    {
+        uint4 v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {                      // 3 tiles x ROWS x 8 chunks = 768 NT = 12 x (64 NT threads)
+            const int c = tid + i * 64 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            const int rr = row < T ? row : T - 1;           // clamped, not predicated: the loads all issue back to back
+            v[i] = *reinterpret_cast<const uint4*>(Qg + (size_t)rr * rs + (size_t)tile * os + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = tid + i * 64 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            *reinterpret_cast<uint4*>(smem + tile * IMG + img_off(row, ch)) = row < T ? v[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
     __syncthreads();
 
     // S^T tiles: rows = keys (regs), cols = queries (lanes)
-    f32x16 st[MT];
+    f32x16 st[NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) st[t] = zero16();
-    const int qrow = 32 * qb + r;
+    for (int t = 0; t < NT; ++t) st[t] = zero16();
+    const int qrow = 32 * w + r;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        const bf16x8 bq = qrow < T ? ld8(Qg + (size_t)qrow * rs + 16 * s + 8 * hh) : zero8();
+        const bf16x8 bq = img_row(Qi, qrow, 2 * s + hh);
 #pragma unroll
-        for (int t = 0; t < MT; ++t)
-            if (t < NK) {
-                const bf16x8 a = 32 * t + r < T ? ld8(Kg + (size_t)(32 * t + r) * rs + 16 * s + 8 * hh) : zero8();
-                st[t] = MFMA_BF16(a, bq, st[t]);
-            }
+        for (int t = 0; t < NT; ++t) st[t] = MFMA_BF16(img_row(Ki, 32 * t + r, 2 * s + hh), bq, st[t]);
     }
     float m = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int key = 32 * t + crow(g, hh);
@@ -136,7 +212,7 @@ __global__ __launch_bounds__(64 * MT) void attn_fwd_bf16_kernel(const bf16_t* __
     m = fmaxf(m, __shfl_xor(m, 32));
     float sum = 0.f;
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             st[t][g] = __expf(st[t][g] - m);
@@ -145,27 +221,20 @@ __global__ __launch_bounds__(64 * MT) void attn_fwd_bf16_kernel(const bf16_t* __
     sum += __shfl_xor(sum, 32);
     const float inv = 1.0f / sum;
 
+    // O^T = V^T . P^T: the probability accumulators are the B operand as they stand (k = key in permk order), V^T comes out of
+    // the V image by transposed reads; the result has d in registers (4 consecutive per quad) and the query on the lane.
     f32x16 o0 = zero16(), o1 = zero16();
+    const int cb = 16 * ((lane >> 4) & 1);
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
-        if (t < NK) {
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const bf16x8 p = cvt8(st[t], s, inv);
-                o0 = MFMA_BF16(p, ld8_col_perm(Vs, VLD, 32 * t, s, hh, r), o0);
-                o1 = MFMA_BF16(p, ld8_col_perm(Vs, VLD, 32 * t, s, hh, 32 + r), o1);
-            }
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 p = cvt8(st[t], s, inv);
+            o0 = MFMA_BF16(img_tr8(Vi, 32 * t, s, hh, cb, lane), p, o0);
+            o1 = MFMA_BF16(img_tr8(Vi, 32 * t, s, hh, 32 + cb, lane), p, o1);
         }
-    // O tile: rows = queries (regs), cols = d (lanes)
-    bf16_t* og = out + (size_t)b * T * H * HD + (size_t)h * HD;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) {
-        const int q = 32 * qb + crow(g, hh);
-        if (q < T) {
-            og[(size_t)q * H * HD + r] = (bf16_t)o0[g];
-            og[(size_t)q * H * HD + 32 + r] = (bf16_t)o1[g];
-        }
-    }
+    // this wave's Q rows are read by nobody else: stage the output tile there and write whole rows
+    store_tile_t(Qi, 32 * w, o0, o1, lane, out + (size_t)b * T * os + (size_t)h * HD, os, T);
     if (lse && hh == 0 && qrow < T) lse[((size_t)b * H + h) * T + qrow] = m + logf(sum);
 }
 
@@ -246,70 +315,87 @@ __global__ __launch_bounds__(64 * MT) void attn_fwd_f32_kernel(const float* __re
 }
 
 // ===================================================================== backward, bf16
-// LDS (dynamic): Q,K,V,dO tiles (ROWS x VLD bf16 each) + lse[ROWS] + delta[ROWS].
-template <int MT>
-__global__ __launch_bounds__(128 * MT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
+// LDS (dynamic): Q, K, V, dO images (ROWS x 128 B each) + lse[ROWS] + delta[ROWS].  2 NT waves: waves 0..NT-1 each own one key
+// tile (dK, dV), waves NT..2NT-1 each own one query tile (dQ) -- the two phases of a (b,h) problem run side by side.  Every
+// gradient tile is produced TRANSPOSED (d in registers, key / query on the lane: X^T = M^T . Y with M^T read from an image by
+// transposed reads and the recomputed P / dS accumulators as the B operand), staged through its own image rows and written as
+// whole 128-byte rows.
+template <int NT>
+__global__ __launch_bounds__(128 * NT) void attn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ out,
                                                                 const bf16_t* __restrict__ dout, const float* __restrict__ lse,
                                                                 bf16_t* __restrict__ dqkv, int T, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    constexpr int ROWS = 32 * MT;
-    bf16_t* Qs = reinterpret_cast<bf16_t*>(sm);
-    bf16_t* Ks = Qs + ROWS * VLD;
-    bf16_t* Vs = Ks + ROWS * VLD;
-    bf16_t* Ds = Vs + ROWS * VLD;
-    float* Ls = reinterpret_cast<float*>(Ds + ROWS * VLD);
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWS = 32 * NT, IMG = ROWS * 128;
+    unsigned char* Qi = smem;
+    unsigned char* Ki = Qi + IMG;
+    unsigned char* Vi = Ki + IMG;
+    unsigned char* Di = Vi + IMG;
+    float* Ls = reinterpret_cast<float*>(Di + IMG);
     float* Del = Ls + ROWS;
     const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
     const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
     const bf16_t* Og = out + (size_t)b * T * os + (size_t)h * HD;
     const bf16_t* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
-    const int NT = (T + 31) >> 5;  // number of 32-row tiles (= waves)
-
-    stage_bf16(Qs, Qg, rs, T, ROWS);
-    stage_bf16(Ks, Qg + os, rs, T, ROWS);
-    stage_bf16(Vs, Qg + 2 * os, rs, T, ROWS);
-    stage_bf16(Ds, Dg, os, T, ROWS);
-    {   // delta[q] = sum_d dO[q][d] * O[q][d]; two threads per row
-        const int q = tid >> 1, half = tid & 1;
-        float acc = 0.f;
-        if (q < T) {
+    {
+        uint4 v[6], d[2], o[2];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const bf16x8 o8 = ld8(Og + (size_t)q * os + half * 32 + c * 8);
-                const bf16x8 d8 = ld8(Dg + (size_t)q * os + half * 32 + c * 8);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc += (float)o8[j] * (float)d8[j];
-            }
+        for (int i = 0; i < 6; ++i) {                       // Q, K, V: 3 x ROWS x 8 chunks = 768 NT = 6 x (128 NT threads)
+            const int c = tid + i * 128 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            const int rr = row < T ? row : T - 1;
+            v[i] = *reinterpret_cast<const uint4*>(Qg + (size_t)rr * rs + (size_t)tile * os + ch * 8);
         }
-        acc += __shfl_xor(acc, 1);
-        if (half == 0 && q < ROWS) {
-            Del[q] = acc;
-            Ls[q] = q < T ? lse[((size_t)b * H + h) * T + q] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                       // dO and O: ROWS x 8 chunks = 2 x (128 NT threads)
+            const int c = tid + i * 128 * NT, row = c >> 3, ch = c & 7;
+            const int rr = row < T ? row : T - 1;
+            d[i] = *reinterpret_cast<const uint4*>(Dg + (size_t)rr * os + ch * 8);
+            o[i] = *reinterpret_cast<const uint4*>(Og + (size_t)rr * os + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int c = tid + i * 128 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            *reinterpret_cast<uint4*>(smem + tile * IMG + img_off(row, ch)) = row < T ? v[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * 128 * NT, row = c >> 3, ch = c & 7;
+            const uint4 dz = row < T ? d[i] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(Di + img_off(row, ch)) = dz;
+            // delta[q] = sum_d dO[q][d] * O[q][d]: the 8 lanes that hold a row's chunks meet by lane exchange
+            const bf16x8 d8 = *reinterpret_cast<const bf16x8*>(&dz), o8 = *reinterpret_cast<const bf16x8*>(&o[i]);
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc += (float)o8[j] * (float)d8[j];
+            acc += __shfl_xor(acc, 1);
+            acc += __shfl_xor(acc, 2);
+            acc += __shfl_xor(acc, 4);
+            if (ch == 0) {
+                Del[row] = acc;
+                Ls[row] = row < T ? lse[((size_t)b * H + h) * T + row] : 0.f;
+            }
         }
     }
     __syncthreads();
 
     bf16_t* dQg = dqkv + (size_t)b * T * rs + (size_t)h * HD;
-    bf16_t* dKg = dQg + os;
-    bf16_t* dVg = dKg + os;
-
-    // The workgroup has 2*NT waves: waves 0..NT-1 each own one key tile (phase A: dK, dV), waves NT..2NT-1 each own one query
-    // tile (phase B: dQ) -- the two phases of a (b,h) problem run side by side instead of one after the other.
+    const int cb = 16 * ((lane >> 4) & 1);
+    f32x16 x0 = zero16(), x1 = zero16(), y0 = zero16(), y1 = zero16();      // A: dV^T, dK^T;  B: dQ^T (y unused)
     // ---- phase A: this wave owns key tile kt.  Tiles X[q][key]: rows = q (regs), cols = key (lanes).
     if (w < NT) {
         const int kt = w;
         const int key = 32 * kt + r;
-        f32x16 dv0 = zero16(), dv1 = zero16(), dk0 = zero16(), dk1 = zero16();
         for (int qt = 0; qt < NT; ++qt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int d0 = 16 * ks + 8 * hh;
-                s = MFMA_BF16(ld8(Qs + (32 * qt + r) * VLD + d0), ld8(Ks + key * VLD + d0), s);
-                dp = MFMA_BF16(ld8(Ds + (32 * qt + r) * VLD + d0), ld8(Vs + key * VLD + d0), dp);
+                const int ch = 2 * ks + hh;
+                s = MFMA_BF16(img_row(Qi, 32 * qt + r, ch), img_row(Ki, key, ch), s);
+                dp = MFMA_BF16(img_row(Di, 32 * qt + r, ch), img_row(Vi, key, ch), dp);
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -319,23 +405,13 @@ __global__ __launch_bounds__(128 * MT) void attn_bwd_bf16_kernel(const bf16_t* _
                 dp[g] = p * (dp[g] - Del[q]);   // dS[q][key]
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {  // sum over q (X rows): X^T . B, B[k=q][col=d]
+            for (int ks = 0; ks < 2; ++ks) {  // sum over q (X rows): M^T . X, M^T[i = d][k = q] by transposed reads
                 const bf16x8 pa = cvt8(s, ks, 1.0f);
                 const bf16x8 da = cvt8(dp, ks, scale);
-                dv0 = MFMA_BF16(pa, ld8_col_perm(Ds, VLD, 32 * qt, ks, hh, r), dv0);
-                dv1 = MFMA_BF16(pa, ld8_col_perm(Ds, VLD, 32 * qt, ks, hh, 32 + r), dv1);
-                dk0 = MFMA_BF16(da, ld8_col_perm(Qs, VLD, 32 * qt, ks, hh, r), dk0);
-                dk1 = MFMA_BF16(da, ld8_col_perm(Qs, VLD, 32 * qt, ks, hh, 32 + r), dk1);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {  // result rows = keys (regs), cols = d (lanes)
-            const int kk = 32 * kt + crow(g, hh);
-            if (kk < T) {
-                dVg[(size_t)kk * rs + r] = (bf16_t)dv0[g];
-                dVg[(size_t)kk * rs + 32 + r] = (bf16_t)dv1[g];
-                dKg[(size_t)kk * rs + r] = (bf16_t)dk0[g];
-                dKg[(size_t)kk * rs + 32 + r] = (bf16_t)dk1[g];
+                x0 = MFMA_BF16(img_tr8(Di, 32 * qt, ks, hh, cb, lane), pa, x0);            // dV^T[d][key]
+                x1 = MFMA_BF16(img_tr8(Di, 32 * qt, ks, hh, 32 + cb, lane), pa, x1);
+                y0 = MFMA_BF16(img_tr8(Qi, 32 * qt, ks, hh, cb, lane), da, y0);            // dK^T[d][key]
+                y1 = MFMA_BF16(img_tr8(Qi, 32 * qt, ks, hh, 32 + cb, lane), da, y1);
             }
         }
     }
@@ -344,14 +420,13 @@ __global__ __launch_bounds__(128 * MT) void attn_bwd_bf16_kernel(const bf16_t* _
         const int qt = w - NT;
         const int q = 32 * qt + r;
         const float lq = Ls[q], dq_ = Del[q];
-        f32x16 dq0 = zero16(), dq1 = zero16();
         for (int kt = 0; kt < NT; ++kt) {
             f32x16 s = zero16(), dp = zero16();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int d0 = 16 * ks + 8 * hh;
-                s = MFMA_BF16(ld8(Ks + (32 * kt + r) * VLD + d0), ld8(Qs + q * VLD + d0), s);
-                dp = MFMA_BF16(ld8(Vs + (32 * kt + r) * VLD + d0), ld8(Ds + q * VLD + d0), dp);
+                const int ch = 2 * ks + hh;
+                s = MFMA_BF16(img_row(Ki, 32 * kt + r, ch), img_row(Qi, q, ch), s);
+                dp = MFMA_BF16(img_row(Vi, 32 * kt + r, ch), img_row(Di, q, ch), dp);
             }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -360,20 +435,19 @@ __global__ __launch_bounds__(128 * MT) void attn_bwd_bf16_kernel(const bf16_t* _
                 dp[g] = p * (dp[g] - dq_);  // dS^T[key][q]
             }
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {  // sum over key (X' rows): X'^T . B, B[k=key][col=d]
+            for (int ks = 0; ks < 2; ++ks) {  // sum over key: K^T . dS^T
                 const bf16x8 da = cvt8(dp, ks, scale);
-                dq0 = MFMA_BF16(da, ld8_col_perm(Ks, VLD, 32 * kt, ks, hh, r), dq0);
-                dq1 = MFMA_BF16(da, ld8_col_perm(Ks, VLD, 32 * kt, ks, hh, 32 + r), dq1);
+                x0 = MFMA_BF16(img_tr8(Ki, 32 * kt, ks, hh, cb, lane), da, x0);            // dQ^T[d][q]
+                x1 = MFMA_BF16(img_tr8(Ki, 32 * kt, ks, hh, 32 + cb, lane), da, x1);
             }
         }
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int qq = 32 * qt + crow(g, hh);
-            if (qq < T) {
-                dQg[(size_t)qq * rs + r] = (bf16_t)dq0[g];
-                dQg[(size_t)qq * rs + 32 + r] = (bf16_t)dq1[g];
-            }
-        }
+    }
+    __syncthreads();            // every wave has finished reading the images: they become the staging area of the results
+    if (w < NT) {
+        store_tile_t(Vi, 32 * w, x0, x1, lane, dQg + 2 * os, rs, T);
+        store_tile_t(Ki, 32 * w, y0, y1, lane, dQg + os, rs, T);
+    } else {
+        store_tile_t(Qi, 32 * (w - NT), x0, x1, lane, dQg, rs, T);
     }
 }
 
@@ -520,12 +594,15 @@ extern "C" int gm3d_attention_fwd(const void* qkv, void* out, float* lse, int B,
     if (rc != GM3D_OK) return rc;
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int threads = 64 * ((T + 31) / 32);
-    const int rows = T <= 64 ? 64 : 128;
+    const int nt = (T + 31) / 32;
     if (dtype == GM3D_BF16) {
-        return T <= 64 ? launch_attn(attn_fwd_bf16_kernel<2>, B * H, threads, 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale)
-                       : launch_attn(attn_fwd_bf16_kernel<4>, B * H, threads, 0, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale);
+        const size_t lds = (size_t)3 * 32 * nt * 128;
+#define GM3D_AF(NT_) launch_attn(attn_fwd_bf16_kernel<NT_>, B * H, 64 * NT_, lds, st, (const bf16_t*)qkv, (bf16_t*)out, lse, T, H, scale)
+        return nt == 1 ? GM3D_AF(1) : nt == 2 ? GM3D_AF(2) : nt == 3 ? GM3D_AF(3) : GM3D_AF(4);
+#undef GM3D_AF
     }
+    const int threads = 64 * nt;
+    const int rows = T <= 64 ? 64 : 128;
     const size_t lds = sizeof(float) * 3 * rows * 64;
     return T <= 64 ? launch_attn(attn_fwd_f32_kernel<2>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale)
                    : launch_attn(attn_fwd_f32_kernel<4>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale);
@@ -539,15 +616,17 @@ extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* 
     if (!dout || !lse || !dqkv) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int threads = 128 * ((T + 31) / 32);   // NT key-tile waves + NT query-tile waves
-    const int rows = T <= 64 ? 64 : 128;
+    const int nt = (T + 31) / 32;
     if (dtype == GM3D_BF16) {
-        const size_t lds = (size_t)4 * rows * VLD * sizeof(bf16_t) + 2 * rows * sizeof(float);
-        return T <= 64 ? launch_attn(attn_bwd_bf16_kernel<2>, B * H, threads, lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale)
-                       : launch_attn(attn_bwd_bf16_kernel<4>, B * H, threads, lds, st, (const bf16_t*)qkv, (const bf16_t*)out,
-                                     (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, scale);
+        const size_t lds = (size_t)4 * 32 * nt * 128 + 2 * 32 * nt * sizeof(float);
+#define GM3D_AB(NT_)                                                                                                      \
+    launch_attn(attn_bwd_bf16_kernel<NT_>, B * H, 128 * NT_, lds, st, (const bf16_t*)qkv, (const bf16_t*)out, (const bf16_t*)dout, lse, \
+                (bf16_t*)dqkv, T, H, scale)
+        return nt == 1 ? GM3D_AB(1) : nt == 2 ? GM3D_AB(2) : nt == 3 ? GM3D_AB(3) : GM3D_AB(4);
+#undef GM3D_AB
     }
+    const int threads = 128 * nt;   // NT key-tile waves + NT query-tile waves
+    const int rows = T <= 64 ? 64 : 128;
     const size_t lds = sizeof(float) * (4 * rows * 64 + 2 * rows);
     return T <= 64 ? launch_attn(attn_bwd_f32_kernel<2>, B * H, threads, lds, st, (const float*)qkv, (const float*)out,
                                  (const float*)dout, lse, (float*)dqkv, T, H, scale)
