@@ -49,6 +49,8 @@ def algorithmic(name, meta):
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
     if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMM (+ epilogues): 2*M*N*K flop
         return "mfma", 2.0 * meta["M"] * meta["N"] * meta["K"], "FLOP"
+    if name == "gm3d_gemm_nt_bf16":            # own weight-gradient GEMM, batched: 2*B*R*N*K flop (meta M = reduction rows)
+        return "mfma", 2.0 * meta["B"] * meta["M"] * meta["N"] * meta["K"], "FLOP"
     sz = 2 if "bfloat16" in str(meta.get("dtype", "")) else 4
     if name == "gm3d_residual_ln_fwd":   # res in/out fp32, y + add in, h out
         return "hbm", meta["R"] * 384 * (8 + 3 * sz), "B"

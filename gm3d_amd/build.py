@@ -25,6 +25,8 @@ SOURCES = {
     "embed.hip": [],
     "optim.hip": [],
     "gemm.hip": [],
+    "gemm_nt.hip": [],
+    "attention_masked.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,0 +1,194 @@
+// dW[b][n][k] = sum_r dY[b][r][n] * X[b][r][k]  -- the weight-gradient GEMMs of the path: bf16 operands that are BOTH row-major
+// with the reduction index r (token / point rows: 2048 .. 262,144 of them) as the slow dimension, fp32 result (N, K = 128 .. 1536)
+// written straight into the parameters' slots of the optimizer's flat gradient buffer, batched over the blocks of a stack.
+//
+// Beneath: the .grad of every nn.Linear / Conv1d(k=1) weight on the path -- timm Block qkv / proj / fc1 / fc2 (in-tree twin
+// Point-MAE_SA3D/models/Point_MAE.py:82-125) and the mini-PointNet convs (models_mae_learn_loss.py:873-882) -- which the
+// reference leaves to autograd (addmm backward: one cuBLAS NT GEMM per weight per step).
+//
+// Design (MI355X).  Neither operand has the reduction index contiguous, which is what an MFMA fragment wants (8 consecutive k
+// per lane).  Both are therefore staged as they lie in memory -- [32 rows][128 columns] bf16 tiles with coalesced 16-byte
+// pieces, by LDS-DMA (global_load_lds_dwordx4: no staging registers, four tiles deep, two stages in flight behind a COUNTED
+// s_waitcnt vmcnt) -- and every fragment is read with the hardware-transposing ds_read_b64_tr_b16 (4 rows x 16 columns per
+// 16-lane group, column-major out).  The LDS image is the 256-byte-row image with the chunk XOR
+// ((row & 3) << 2 | (row >> 2) & 3) (conflict-free transposed reads); LDS-DMA writes lane-linear, so the XOR sits on the
+// per-lane SOURCE address.  128 x 128 output tile per 256-thread workgroup (4 waves x (64 x 64) = 2 x 2 MFMA 32x32x16 tiles),
+// 64 KiB of LDS -> two workgroups per CU.  Long reductions over few output tiles (the 4-block decoders: 27 tiles per
+// weight kind and block) are split over row ranges into fp32 partial slabs that gm3d_sum_few_rows adds in a fixed order
+// (deterministic; no atomics).
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 nbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 nbf16x4 __attribute__((ext_vector_type(4)));
+typedef float nf32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) nbf16x4 lds_nbf16x4;
+
+constexpr int NT_BR = 32;                 // reduction rows per stage
+constexpr int NT_TILE = NT_BR * 256;      // bytes of one [32][128] bf16 tile
+constexpr int NT_STAGE = 2 * NT_TILE;     // dY tile + X tile
+constexpr int NT_NBUF = 4;
+
+__device__ __forceinline__ int nt_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
+
+// one LDS-DMA piece: 64 lanes x 16 bytes -> 1 KiB at the wave-uniform LDS byte address `dst`; the compiler does not see this
+// load (no automatic s_waitcnt vmcnt(0) before the next LDS read): completion is counted by hand below
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// fragment for mfma_32x32x16 out of a [32 rows][128 cols] image: element j of this lane = M[k = kk0 + 8 hh + j][col], the lane's
+// column being colblk + (lane & 15), colblk a multiple of 16 that already includes this lane's 16-lane group
+__device__ __forceinline__ nbf16x8 nt_frag(const unsigned char* img, int kk0, int hh, int colblk, int lane) {
+    const int l16 = lane & 15, q = l16 >> 2, p = l16 & 3;
+    const int col = colblk + 4 * p, ch = col >> 3, sub = (col >> 2) & 1;
+    const int r0 = kk0 + 8 * hh + q, r1 = r0 + 4;
+    const nbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_nbf16x4*)(img + 256 * r0 + 16 * (ch ^ nt_f(r0)) + 8 * sub));
+    const nbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_nbf16x4*)(img + 256 * r1 + 16 * (ch ^ nt_f(r1)) + 8 * sub));
+    nbf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    return v;
+}
+
+// grid.x = batch * splits * tiles_n * tiles_k (rounded up to a multiple of 8, XCD-aware order).  Rows of split s:
+// [s * rows_split, (s + 1) * rows_split); rows_split % 32 == 0.
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
+                                                              float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
+                                                              long long sY, long long sX, long long sO, long long sOs, int splits,
+                                                              int tiles_n, int tiles_k, int total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    int t = logical;
+    const int tk = t % tiles_k; t /= tiles_k;
+    const int tn = t % tiles_n; t /= tiles_n;
+    const int sp = t % splits;
+    const int b = t / splits;
+    const int n0 = tn * 128, k0 = tk * 128;
+    const bf16_t* Yb = Y + (size_t)b * sY + (size_t)sp * rows_split * ldy + n0;
+    const bf16_t* Xb = X + (size_t)b * sX + (size_t)sp * rows_split * ldx + k0;
+    float* Ob = O + (size_t)b * sO + (size_t)sp * sOs;
+    const int nst = rows_split / NT_BR;
+
+    // staging role of this lane: each wave moves pieces w and w + 4 of both tiles (a piece = 4 rows x 256 B = 1 KiB)
+    const int prow = lane >> 4, pcs = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)nsm;
+    size_t yoff[2], xoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 4 * (w + 4 * i) + prow;                    // row inside the stage's 32
+        const int ch = pcs ^ nt_f(row);                            // the chunk that belongs at LDS slot pcs of this row
+        yoff[i] = (size_t)row * ldy + ch * 8;
+        xoff[i] = (size_t)row * ldx + ch * 8;
+    }
+#define GM3D_NT_STAGE(ST)                                                                                    \
+    {                                                                                                        \
+        const unsigned base = lds0 + ((ST) % NT_NBUF) * NT_STAGE;                                            \
+        const size_t ro = (size_t)(ST) * NT_BR;                                                              \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                      \
+            glds16(Yb + ro * ldy + yoff[i], base + 1024 * (w + 4 * i));                                      \
+            glds16(Xb + ro * ldx + xoff[i], base + NT_TILE + 1024 * (w + 4 * i));                            \
+        }                                                                                                    \
+    }
+
+    nf32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+    const int wn = (w >> 1) * 64, wk = (w & 1) * 64;
+    const int cb = 16 * ((lane >> 4) & 1);
+
+    GM3D_NT_STAGE(0)
+    if (nst > 1) GM3D_NT_STAGE(1)
+    for (int st = 0; st < nst; ++st) {
+        // every wave issues 4 pieces per stage: stage st has landed (this wave's share) when at most the pieces of the stages
+        // issued after it are outstanding
+        if (st + 2 < nst) {
+            GM3D_NT_STAGE(st + 2)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (st + 1 < nst) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();                   // ... and everybody else's share
+        const unsigned char* ys = nsm + (st % NT_NBUF) * NT_STAGE;
+        const unsigned char* xs = ys + NT_TILE;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            nbf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = nt_frag(ys, 16 * ks, hh, wn + 32 * i + cb, lane);      // A[i = n][k = row]
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = nt_frag(xs, 16 * ks, hh, wk + 32 * j + cb, lane);      // B[k = row][j = k col]
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        // buffer (st + 3) % 4 is restaged by the NEXT iteration's issue; every wave is past its reads of it (stage st - 1)
+        // once it has passed this iteration's barrier, and a wave reaches the next issue only after its own reads of stage st
+        // have returned (the MFMAs above consumed them)
+    }
+#undef GM3D_NT_STAGE
+    // result: rows (registers) = n, columns (lanes) = k: 128 contiguous bytes per half-wave and register
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = n0 + wn + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                Ob[(size_t)n * ldo + k0 + wk + 32 * j + r] = acc[i][j][g];
+            }
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_gemm_nt_splits(int batch, int R, int N, int K) {
+    // the smallest power-of-two row split (<= 64, gm3d_sum_few_rows' limit) that offers the chip >= 512 workgroups while every
+    // split keeps >= 512 rows (16 stages)
+    if (batch < 1 || R < 1 || N < 1 || K < 1) return 1;
+    const long long tiles = (long long)batch * (N / 128) * (K / 128);
+    int s = 1;
+    while (tiles * s < 512 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 512) s *= 2;
+    return s;
+}
+
+extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int batch, int R, int N, int K, int ldy, int ldx, int ldo,
+                                 long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split,
+                                 gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dY || !X || !out || batch < 0 || R < 1 || N < 1 || K < 1 || splits < 1) return GM3D_EINVAL;
+    if (N % 128 || K % 128 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldo < K) return GM3D_EUNSUPPORTED;
+    if (R % (NT_BR * splits)) return GM3D_EUNSUPPORTED;
+    if (((size_t)dY | (size_t)X) & 15) return GM3D_EUNSUPPORTED;
+    if (splits > 1 && stride_split < (long long)N * ldo) return GM3D_EINVAL;
+    if (batch == 0) return GM3D_OK;
+    const long long total = (long long)batch * splits * (N / 128) * (K / 128);
+    if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    const int grid = (int)((total + 7) / 8 * 8);
+    const size_t lds = (size_t)NT_NBUF * NT_STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return GM3D_ELAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dY, (const bf16_t*)X, out,
+                       R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, N / 128, K / 128, (int)total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

@@ -42,6 +42,9 @@ def splitk_wgrad(dy, x):
     """dW (N,K) f32 = dy (R,N)^T @ x (R,K) with R split into SPLITK batched chunks + a deterministic sum."""
     R, N = dy.shape
     K = x.shape[1]
+    from . import gemm
+    if dy.is_contiguous() and x.is_contiguous() and gemm.wgrad_supported(dy.unsqueeze(0), x.unsqueeze(0)):
+        return gemm.wgrad_nt(dy.unsqueeze(0), x.unsqueeze(0))[0]      # hand-written NT kernel (row split chosen by shape)
     S = SPLITK if R % SPLITK == 0 and R >= 64 * SPLITK else 1
     a = dy.view(S, R // S, N).transpose(1, 2)
     b = x.view(S, R // S, K)

@@ -191,6 +191,8 @@ def _wgrad_batched(dy, x, out=None):
     256 CUs -- 50 us each through hipBLASLt -- while the batch over blocks runs at ~16 us per block.)"""
     nblk, R, N = dy.shape
     K = x.shape[2]
+    if gemm.wgrad_supported(dy, x) and (out is None or (out.stride(2) == 1 and out.stride(1) == K and out.stride(0) == N * K)):
+        return gemm.wgrad_nt(dy, x, out)       # hand-written NT kernel: LDS-DMA staging + transposed LDS reads (csrc/gemm_nt.hip)
     S = WGRAD_ROW_SPLIT
     if S == 0:      # auto: the smallest split that gives the chip >= 512 output tiles of 128x128 while keeping >= 512 rows each
         S, tiles = 1, nblk * max(N // 128, 1) * max(K // 128, 1)
@@ -306,6 +308,17 @@ class TransformerStackFn(torch.autograd.Function):
 
     @staticmethod
     def _forward(ctx, x, pos, meta, final_w, final_b, *params):
+        g = TransformerStackFn._forward_gen(ctx, x, pos, meta, final_w, final_b, *params)
+        while True:
+            try:
+                next(g)
+            except StopIteration as done:
+                return done.value
+
+    @staticmethod
+    def _forward_gen(ctx, x, pos, meta, final_w, final_b, *params):
+        """The forward as a generator that yields after every kernel launch: run_stack drives several half-batch chains in
+        lock-step, one launch of each in turn on its own stream, so that a captured graph holds them as interleaved branches."""
         B, T, C = x.shape
         assert C == LNC and len(params) % PER_BLOCK == 0
         nblk = len(params) // PER_BLOCK
@@ -331,10 +344,15 @@ class TransformerStackFn(torch.autograd.Function):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             dp1, dp2 = meta["dp"][i]
             u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
+            yield
             qkv = _mm(h1, weight_cache.get(wqkv, adt))
+            yield
             a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
+            yield
             p = _mm(a, weight_cache.get(wproj, adt))
+            yield
             x1, h2, m2, r2 = residual_ln_fwd(u, p, bproj, dp1, T, None, ln2w, ln2b, eps, adt, R, h=H2[i] if need else None)
+            yield
             W1 = weight_cache.get(w1, adt)
             if gemm.FUSE_GELU and gemm.supported(h2, W1):
                 # fc1 + bias + GELU in the GEMM epilogue; the pre-activation is only written when a backward follows
@@ -342,8 +360,11 @@ class TransformerStackFn(torch.autograd.Function):
                                         g_out=GG[i] if need else None)
             else:
                 f = h2 @ W1.t()
+                yield
                 g = bias_gelu_fwd(f, b1, adt, g=GG[i] if need else None)
+            yield
             o = g @ weight_cache.get(w2, adt).t()
+            yield
             if need:
                 saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
             res, y, bias, rs = x1, o, b2, dp2
@@ -500,22 +521,49 @@ def run_stack(blocks, final_norm, x, pos, training):
         h = B // ns
         x, pos = x.contiguous(), pos.contiguous()
         outs = [None] * ns
-        for j in range(1, ns):
-            side = _split_stream(x.device, j)
+        streams = [main] + [_split_stream(x.device, j) for j in range(1, ns)]
+        for side in streams[1:]:
             side.wait_stream(main)
-            with torch.cuda.stream(side):
-                outs[j] = TransformerStackFn.apply(x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h], meta, final_norm.weight, final_norm.bias,
-                                                   *params)
             x.record_stream(side)
             pos.record_stream(side)
-        outs[0] = TransformerStackFn.apply(x[:h], pos[:h], meta, final_norm.weight, final_norm.bias, *params)
+        if LOCKSTEP:
+            # one launch of every chain in turn: the capture (and the graph executor's enqueue order) interleaves the branches
+            with torch.autocast("cuda", enabled=False), torch.no_grad():
+                gens = [TransformerStackFn._forward_gen(_NoCtx(), x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h], meta, final_norm.weight,
+                                                        final_norm.bias, *params) for j in range(ns)]
+                live = ns
+                while live:
+                    for j in range(ns):
+                        if gens[j] is None:
+                            continue
+                        with torch.cuda.stream(streams[j]):
+                            try:
+                                next(gens[j])
+                            except StopIteration as done:
+                                outs[j], gens[j] = done.value, None
+                                live -= 1
+        else:
+            for j in range(1, ns):
+                with torch.cuda.stream(streams[j]):
+                    outs[j] = TransformerStackFn.apply(x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h], meta, final_norm.weight,
+                                                       final_norm.bias, *params)
+            outs[0] = TransformerStackFn.apply(x[:h], pos[:h], meta, final_norm.weight, final_norm.bias, *params)
         for j in range(1, ns):
-            main.wait_stream(_split_stream(x.device, j))
+            main.wait_stream(streams[j])
             outs[j].record_stream(main)
         return torch.cat(outs, dim=0)
     return TransformerStackFn.apply(x, pos, meta, final_norm.weight, final_norm.bias, *params)
 
 
+class _NoCtx:
+    """stand-in for the autograd context in the inference-only lock-step driver (nothing is saved)."""
+    needs_input_grad = ()
+
+    def save_for_backward(self, *a):
+        pass
+
+
+LOCKSTEP = __import__("os").environ.get("GM3D_LOCKSTEP", "1") == "1"     # interleave the launches of the parallel inference chains
 NOGRAD_SPLIT = int(__import__("os").environ.get("GM3D_NOGRAD_SPLIT", "2"))    # parallel chains of an inference-only stack (1 = off)
 _split_streams = {}
 

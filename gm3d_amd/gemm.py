@@ -73,6 +73,43 @@ def linear_pool(x, w, bias, bias_after_pool, want_rows):
     return rows, pooled, arg
 
 
+OWN_WGRAD = os.environ.get("GM3D_OWN_WGRAD", "1") == "1"     # weight-gradient (NT) GEMMs on the hand-written kernel (csrc/gemm_nt.hip)
+
+
+def wgrad_supported(dy, x):
+    """dy (nb,R,N), x (nb,R,K) bf16 with unit inner stride and a common batch layout; N, K % 128 == 0, R % 32 == 0."""
+    return (ENABLED and OWN_WGRAD and dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 3
+            and x.dim() == 3 and dy.shape[:2] == x.shape[:2] and dy.shape[2] % 128 == 0 and x.shape[2] % 128 == 0
+            and dy.shape[1] % 32 == 0 and dy.stride(2) == 1 and x.stride(2) == 1 and dy.stride(1) % 8 == 0 and x.stride(1) % 8 == 0
+            and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and (dy.shape[0] == 1 or (dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)))
+
+
+def wgrad_nt(dy, x, out=None, splits=None):
+    """out (nb,N,K) f32 = dy[b]^T @ x[b]  (dy (nb,R,N), x (nb,R,K) bf16) -- every weight gradient of a block stack in one launch,
+    written into `out` (the parameters' slots of the flat gradient buffer) when given.  Long reductions over few output tiles
+    are cut into `splits` row ranges whose fp32 partial products are added in a fixed order by gm3d_sum_few_rows."""
+    nb, R, N = dy.shape
+    K = x.shape[2]
+    if splits is None:
+        splits = lib.gm3d_gemm_nt_splits(nb, R, N, K)
+    if out is None:
+        out = torch.empty(nb, N, K, dtype=torch.float32, device=dy.device)
+    assert out.dtype == torch.float32 and out.stride(2) == 1 and out.stride(1) >= K
+    if splits == 1:
+        _launch("gm3d_gemm_nt_bf16", {"B": nb, "M": R, "N": N, "K": K}, lib.gm3d_gemm_nt_bf16, _ptr(dy), _ptr(x), _ptr(out), nb, R, N, K,
+                dy.stride(1), x.stride(1), out.stride(1), dy.stride(0), x.stride(0), out.stride(0), 1, 0, _stream())
+        return out
+    part = torch.empty(nb, splits, N, K, dtype=torch.float32, device=dy.device)
+    _launch("gm3d_gemm_nt_bf16", {"B": nb, "M": R, "N": N, "K": K}, lib.gm3d_gemm_nt_bf16, _ptr(dy), _ptr(x), _ptr(part), nb, R, N, K,
+            dy.stride(1), x.stride(1), K, dy.stride(0), x.stride(0), splits * N * K, splits, N * K, _stream())
+    if out.is_contiguous() or (out.stride(1) == K and out.stride(0) == N * K):
+        _launch("gm3d_sum_few_rows", {"rows": nb * splits, "cols": N * K}, lib.gm3d_sum_few_rows, _ptr(part), nb, splits, N * K, _ptr(out),
+                _stream())
+    else:
+        out.copy_(part.sum(dim=1))
+    return out
+
+
 def tile_rows(M):
     return lib.gm3d_gemm_tile_rows(int(M))
 

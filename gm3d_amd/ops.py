@@ -310,3 +310,55 @@ class _Attention(torch.autograd.Function):
 def attention(qkv, num_heads, scale):
     """qkv (B,T,3*H*64) = output of the qkv Linear (timm layout (B,T,3,H,64)) -> (B,T,H*64)."""
     return _Attention.apply(qkv, num_heads, scale)
+
+
+def pack_mask(mask):
+    """(B,T,T) bool, True = pair not allowed -> (B,T,ceil(T/32)) int32 bitset for attention_masked (bit j&31 of word j>>5)."""
+    B, T, _ = mask.shape
+    W = (T + 31) // 32
+    m = torch.zeros(B, T, W * 32, dtype=torch.int64, device=mask.device)
+    m[:, :, :T] = mask.to(torch.int64)
+    weights = (torch.ones(32, dtype=torch.int64, device=mask.device) << torch.arange(32, device=mask.device))
+    words = (m.view(B, T, W, 32) * weights).sum(-1)                     # 0 .. 2^32-1
+    return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+class _AttentionMasked(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, bits, num_heads, scale):
+        qkv = qkv.contiguous()
+        if qkv.dtype not in _DT:
+            raise RuntimeError("attention supports float32 and bfloat16, got %s" % qkv.dtype)
+        _require(qkv, None, "qkv")
+        B, T, C3 = qkv.shape
+        hd = C3 // (3 * num_heads)
+        if C3 != 3 * num_heads * hd or hd not in (16, 32, 64):
+            raise RuntimeError("qkv last dim must be 3*num_heads*head_dim with head_dim 16, 32 or 64")
+        if bits is not None and (bits.dtype != torch.int32 or tuple(bits.shape) != (B, T, (T + 31) // 32) or not bits.is_contiguous()
+                                 or not bits.is_cuda):
+            raise RuntimeError("mask bitset must be a contiguous int32 (B,T,ceil(T/32)) GPU tensor (ops.pack_mask)")
+        out = torch.empty(B, T, num_heads * hd, dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty(B, num_heads, T, dtype=torch.float32, device=qkv.device)
+        _launch("gm3d_attention_masked_fwd", {"B": B, "T": T, "H": num_heads, "HD": hd, "dtype": str(qkv.dtype)},
+                lib.gm3d_attention_masked_fwd, _ptr(qkv), _ptr(bits), _ptr(out), _ptr(lse), B, T, num_heads, hd, float(scale),
+                _DT[qkv.dtype], _stream())
+        ctx.save_for_backward(qkv, out, lse, bits)
+        ctx.num_heads, ctx.scale, ctx.hd = num_heads, float(scale), hd
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, bits = ctx.saved_tensors
+        dout = dout.contiguous().to(qkv.dtype)
+        B, T, _ = qkv.shape
+        dqkv = torch.empty_like(qkv)
+        _launch("gm3d_attention_masked_bwd", {"B": B, "T": T, "H": ctx.num_heads, "HD": ctx.hd, "dtype": str(qkv.dtype)},
+                lib.gm3d_attention_masked_bwd, _ptr(qkv), _ptr(bits), _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T,
+                ctx.num_heads, ctx.hd, ctx.scale, _DT[qkv.dtype], _stream())
+        return dqkv, None, None, None
+
+
+def attention_masked(qkv, bits, num_heads, scale):
+    """qkv (B,T,3*H*hd), hd in {16,32,64}, T <= 512; bits = pack_mask(mask) of a SYMMETRIC (B,T,T) bool mask (True = not allowed)
+    or None -> (B,T,H*hd).  A query with no allowed key yields zeros.  (The hierarchical Point-M2AE encoder's attention.)"""
+    return _AttentionMasked.apply(qkv, bits, num_heads, scale)

@@ -339,6 +339,26 @@ int gm3d_token_assemble_bwd(const void *dx_vis, const void *dpos_vis, const void
 /* out (njobs, ncols) f32 = sum over the nrows (<= 64) rows of each job of partial (njobs, nrows, ncols): the S-way row-split
  * weight-gradient partial products.  ncols % 4 == 0. */
 int gm3d_sum_few_rows(const float *partial, int njobs, int nrows, long long ncols, float *out, gm3d_stream_t stream);
+/* Weight-gradient GEMM, batched: out[b] (N,K) f32 = dY[b]^T . X[b] with dY[b] (R,N) and X[b] (R,K) bf16, both row-major with row
+ * pitches ldy / ldx (multiples of 8) and batch strides in elements; out row pitch ldo.  This is the .grad of every Linear /
+ * Conv1d(k=1) weight of the path (P/models/Point_MAE.py:82-125, P/models_mae_learn_loss.py:873-882) -- the reference leaves it
+ * to autograd (one cuBLAS NT GEMM per weight).  N, K multiples of 128, R a multiple of 32 * splits, 16-byte aligned operands.
+ * splits > 1: the rows are cut into `splits` ranges and split s writes its partial product at out + b*stride_o + s*stride_split
+ * (gm3d_sum_few_rows adds them in order); gm3d_gemm_nt_splits suggests a value for a shape. */
+int gm3d_gemm_nt_bf16(const void *dY, const void *X, float *out, int batch, int R, int N, int K, int ldy, int ldx, int ldo,
+                      long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split,
+                      gm3d_stream_t stream);
+int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
+/* Masked multi-head attention of the hierarchical (Point-M2AE) encoder blocks -- SURVEY.md 8f.4; the reference ships only the
+ * hyper-parameters (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: dims 96/192/384, 6 heads, local_radius 0.32/0.64/1.28).
+ * qkv (B,T,3,H,HD) as the qkv Linear emits it, HD in {16,32,64}, T <= 512; mask (B,T,ceil(T/32)) uint32 bitset, bit (j&31) of
+ * word j>>5 of row i set = query i must not attend to key j (NULL: no mask); the mask must be symmetric.  out (B,T,H*HD), lse
+ * (B,H,T) f32 (0 for a query with no allowed key, whose output and gradients are zero).  dtype GM3D_BF16: flash-style MFMA
+ * kernels; GM3D_F32: exact fp32 kernels (parity mode). */
+int gm3d_attention_masked_fwd(const void *qkv, const unsigned *mask, void *out, float *lse, int B, int T, int H, int HD, float scale,
+                              int dtype, gm3d_stream_t stream);
+int gm3d_attention_masked_bwd(const void *qkv, const unsigned *mask, const void *out, const void *dout, const float *lse, void *dqkv,
+                              int B, int T, int H, int HD, float scale, int dtype, gm3d_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -122,3 +122,36 @@ def test_stacked_transpose_strided_view():
     loose = [torch.randn(24, 16, device="cuda").bfloat16() for _ in range(3)]
     out = gemm.stacked_transpose(loose)
     assert all(torch.equal(out[i], loose[i].t()) for i in range(3))
+
+
+@pytest.mark.parametrize("nb,R,N,K", [(12, 3200, 384, 1536), (4, 8192, 1152, 384), (1, 262144, 256, 128), (3, 96, 128, 128),
+                                      (2, 2048, 1536, 384), (1, 102400, 384, 512), (4, 8192, 384, 384)])
+def test_gemm_nt_weight_gradient(nb, R, N, K):
+    """The NT (weight-gradient) kernel -- LDS-DMA staging, transposed LDS reads, optional deterministic row split -- against an fp32
+    torch.mm of the same bf16 operands: fp32 accumulation error only (the products of bf16 numbers are exact in fp32)."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(R + N)
+    dy = torch.randn(nb, R, N, device="cuda", generator=g).bfloat16()
+    x = torch.randn(nb, R, K, device="cuda", generator=g).bfloat16()
+    assert gemm.wgrad_supported(dy, x)
+    want = torch.bmm(dy.float().transpose(1, 2), x.float())
+    scale = float(want.abs().max())
+    for splits in (1, None, 2):
+        if splits == 2 and R % 64:
+            continue
+        got = gemm.wgrad_nt(dy, x, splits=splits)
+        assert got.shape == (nb, N, K) and got.dtype == torch.float32
+        err = float((got - want).abs().max())
+        assert err <= 2e-5 * scale * max(1.0, (R / 4096) ** 0.5), (splits, err, scale)
+    # deterministic: two launches agree bit for bit (no atomics anywhere)
+    assert torch.equal(gemm.wgrad_nt(dy, x), gemm.wgrad_nt(dy, x))
+    # strided operands (a column block of a wider activation) and a destination inside a larger flat buffer
+    if N >= 256:
+        wide = torch.randn(nb, R, N + 128, device="cuda", generator=g).bfloat16()
+        dyv = wide[:, :, 128:]
+        flat = torch.zeros(nb * N * K + 64, device="cuda")
+        out = flat[64:].view(nb, N, K)
+        gemm.wgrad_nt(dyv, x, out)
+        want2 = torch.bmm(dyv.float().transpose(1, 2), x.float())
+        assert float((out - want2).abs().max()) <= 2e-5 * float(want2.abs().max()) * max(1.0, (R / 4096) ** 0.5)
+        assert float(flat[:64].abs().max()) == 0.0
