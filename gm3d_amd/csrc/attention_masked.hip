@@ -428,6 +428,29 @@ __global__ __launch_bounds__(128) void mattn_bwd_f32_kernel(const float* __restr
     }
 }
 
+// mask bitset of one level straight from its centres: bit j of row i set iff token i or j is not visible, or their centres are
+// at squared distance >= radius^2 (same separately rounded fp32 expression as common.hpp::sqdist3 / the oracle).
+// One thread per (b, i, word).
+__global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __restrict__ center, const unsigned char* __restrict__ vis,
+                                                               float radius, int B, int G, int W, unsigned* __restrict__ bits) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long long)B * G * W) return;
+    const int wd = (int)(gid % W), i = (int)((gid / W) % G), b = (int)(gid / ((long long)W * G));
+    const float* c = center + (size_t)b * G * 3;
+    const float r2 = __fmul_rn(radius, radius);
+    const float ax = c[3 * i], ay = c[3 * i + 1], az = c[3 * i + 2];
+    const bool vi = !vis || vis[(size_t)b * G + i];
+    unsigned w = 0;
+    for (int t = 0; t < 32; ++t) {
+        const int j = 32 * wd + t;
+        bool blocked = true;
+        if (j < G && vi && (!vis || vis[(size_t)b * G + j]))
+            blocked = radius > 0.f && sqdist3(ax, ay, az, c[3 * j], c[3 * j + 1], c[3 * j + 2]) >= r2;
+        w |= blocked ? (1u << t) : 0u;
+    }
+    bits[gid] = w;
+}
+
 static int mattn_check(const void* a, const void* b, int B, int T, int H, int HDv, int dtype) {
     if (!a || !b || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
     if (HDv != 16 && HDv != 32 && HDv != 64) return GM3D_EUNSUPPORTED;
@@ -446,6 +469,19 @@ static int mattn_attr(K kernel, size_t lds) {
 }
 
 }  // namespace gm3d
+
+extern "C" int gm3d_radius_mask_bits(const float* center, const unsigned char* vis, float radius, int B, int G, unsigned* bits,
+                                     gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!center || !bits || B < 0 || G < 1) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    const int W = (G + 31) / 32;
+    const long long n = (long long)B * G * W;
+    hipLaunchKernelGGL(radius_mask_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, center, vis, radius,
+                       B, G, W, bits);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
 
 extern "C" int gm3d_attention_masked_fwd(const void* qkv, const unsigned* mask, void* out, float* lse, int B, int T, int H, int HD,
                                          float scale, int dtype, gm3d_stream_t stream) {

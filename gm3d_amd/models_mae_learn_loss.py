@@ -306,6 +306,28 @@ def take(x, ids):
     return torch.gather(x, 1, ix)
 
 
+@torch.no_grad()
+def generate_mask_ids(loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None):
+    """Teacher-guided mask (P/:744-784) plus the id lists split_ids would derive from it, as ONE launch (gm3d_mask_select):
+    -> (mask (B,L) f32 0 keep / 1 remove, vis_ids (B,len_keep) int64, mask_ids (B,L-len_keep) int64).  L <= 64."""
+    from ._capi import lib
+    N, L = loss_pred.shape
+    len_keep = int(L * (1 - mask_ratio))
+    keep_ratio = float((epoch + 1) / total_epoch) * 0.5 if guide else 0.5
+    len_loss = int((L - len_keep) * keep_ratio)
+    dev = loss_pred.device
+    if noise is None:
+        noise = torch.rand(N, L, device=dev)
+    noise = noise.to(dev, torch.float32).contiguous()
+    lp = loss_pred.detach().float().contiguous()
+    mask = torch.empty(N, L, dtype=torch.float32, device=dev)
+    order = torch.empty(N, L, dtype=torch.int64, device=dev)        # [visible ids | masked ids] per sample
+    vis_ids, mask_ids = order[:, :len_keep], order[:, len_keep:]
+    ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
+                len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
+    return mask, vis_ids, mask_ids
+
+
 class MaskedAutoencoderViT(nn.Module):
     """GM3D Point-MAE (P/:30-188 live part).  The image-MAE constructor arguments are accepted and
     ignored, exactly as the reference ignores them for the point-cloud path (hyper-parameters are the
@@ -524,24 +546,8 @@ class MaskedAutoencoderViT(nn.Module):
 
     @torch.no_grad()
     def generate_mask_ids(self, loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None):
-        """generate_mask plus the id lists split_ids would derive from it, as ONE launch (gm3d_mask_select):
-        -> (mask (B,L) f32 0 keep / 1 remove, vis_ids (B,len_keep) int64, mask_ids (B,L-len_keep) int64)."""
-        from ._capi import lib
-        N, L = loss_pred.shape
-        len_keep = int(L * (1 - mask_ratio))
-        keep_ratio = float((epoch + 1) / total_epoch) * 0.5 if guide else 0.5
-        len_loss = int((L - len_keep) * keep_ratio)
-        dev = loss_pred.device
-        if noise is None:
-            noise = torch.rand(N, L, device=dev)
-        noise = noise.to(dev, torch.float32).contiguous()
-        lp = loss_pred.detach().float().contiguous()
-        mask = torch.empty(N, L, dtype=torch.float32, device=dev)
-        order = torch.empty(N, L, dtype=torch.int64, device=dev)        # [visible ids | masked ids] per sample
-        vis_ids, mask_ids = order[:, :len_keep], order[:, len_keep:]
-        ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
-                    len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
-        return mask, vis_ids, mask_ids
+        """generate_mask plus the id lists split_ids would derive from it, as ONE launch (module-level generate_mask_ids)."""
+        return generate_mask_ids(loss_pred, mask_ratio, guide, epoch, total_epoch, noise)
 
     def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False):
         """P/:786-815.  relative=True: pairwise ranking BCE over masked tokens."""

@@ -316,11 +316,24 @@ def pack_mask(mask):
     """(B,T,T) bool, True = pair not allowed -> (B,T,ceil(T/32)) int32 bitset for attention_masked (bit j&31 of word j>>5)."""
     B, T, _ = mask.shape
     W = (T + 31) // 32
-    m = torch.zeros(B, T, W * 32, dtype=torch.int64, device=mask.device)
+    m = torch.ones(B, T, W * 32, dtype=torch.int64, device=mask.device)      # keys past T: blocked (the kernels force them anyway)
     m[:, :, :T] = mask.to(torch.int64)
     weights = (torch.ones(32, dtype=torch.int64, device=mask.device) << torch.arange(32, device=mask.device))
     words = (m.view(B, T, W, 32) * weights).sum(-1)                     # 0 .. 2^32-1
     return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
+
+
+def radius_mask_bits(center, vis, radius):
+    """center (B,G,3) f32, vis (B,G) bool | None -> (B,G,ceil(G/32)) int32 bitset: pair (i,j) blocked iff i or j invisible or their
+    centres are >= radius apart (== pack_mask(~(vis_i & vis_j) | dist2 >= radius^2), in one launch and without the (B,G,G) tensors)."""
+    center = center.detach().contiguous()
+    _require(center, torch.float32, "center")
+    B, G, _ = center.shape
+    v = vis.to(torch.uint8).contiguous() if vis is not None else None
+    bits = torch.empty(B, G, (G + 31) // 32, dtype=torch.int32, device=center.device)
+    _launch("gm3d_radius_mask_bits", {"B": B, "G": G}, lib.gm3d_radius_mask_bits, _ptr(center), _ptr(v), float(radius), B, G, _ptr(bits),
+            _stream())
+    return bits
 
 
 class _AttentionMasked(torch.autograd.Function):

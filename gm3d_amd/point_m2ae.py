@@ -1,0 +1,297 @@
+"""Point-M2AE + GeoMask3D: the hierarchical multi-scale masked auto-encoder of BASELINE config #4 on the
+MI355X-native operators.
+
+The reference ships NO source for this model -- Point-M2AE_SA3D/README.md:1 ("will be released soon"); only the hyper-parameters
+exist (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: N=2048; groups 512x16 / 256x8 / 64x8; encoder dims 96/192/384 with
+5 blocks each, 6 heads, local radii 0.32/0.64/1.28; decoder dims 384/192 with 1 block each, 1 up-block each; mask ratio 0.8).
+The model below follows those numbers and the published Point-M2AE design (Zhang et al., NeurIPS 2022: multi-scale masking by
+back-projecting the coarsest visibility, token embedding of the previous level's features, local-radius attention, hierarchical
+decoder with 3-NN token propagation, Chamfer reconstruction of the masked level-1 patches), with GeoMask3D's teacher / student
+scoring (P/engine_pretrain.py:86-171) put on the COARSEST tokens.  Parity is against our own restatement only
+(oracle/hier_ref.py): "parity unpinned".  Choices the configuration does not fix, stated once:
+
+  * attention between tokens i, j of a level is allowed iff both are visible AND their centres are closer than the level's radius;
+  * every level keeps ALL its tokens in place (static shapes; a masked token is excluded by the attention mask, computes garbage
+    that is discarded, and hands its un-encoded embedding to the next level -- the same information flow as compacting the
+    visible tokens, padding to the batch maximum and scattering back);
+  * GeoMask3D: the loss predictor (same head as P/models_mae_learn_loss.py:152-158,668,677) reads the coarsest decoder stage; a
+    coarse token's target is the mean Chamfer loss of its masked level-1 members; the guided mask is generate_mask of the
+    north-star model (P/:744-784) over the 64 coarsest tokens with this configuration's mask ratio.
+
+Kernels: gm3d_fps / gm3d_knn_group per level, gm3d_knn (3-NN propagation), gm3d_attention_masked_fwd/bwd (T up to 512, head_dim
+16/32/64, bitset mask), gm3d_attention_* (unmasked 64-token stage), gm3d_chamfer_*, gm3d_mask_select, gm3d_rank_loss.  The
+Linear / LayerNorm / BatchNorm layers of the 96- and 192-wide levels are PyTorch modules (library GEMMs).
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import models_mae_learn_loss as M
+from . import ops
+from .hierarchical_group import HierarchicalGroup
+
+
+def radius_mask(center, radius):
+    """(B,G,3) -> (B,G,G) bool, True = centres at distance >= radius (no attention).  Squared distances accumulated coordinate by
+    coordinate in fp32 (separately rounded products and sums: the CPU oracle reproduces every bit)."""
+    d = center.unsqueeze(2) - center.unsqueeze(1)
+    d2 = d[..., 0] * d[..., 0]
+    d2 = d2 + d[..., 1] * d[..., 1]
+    d2 = d2 + d[..., 2] * d[..., 2]
+    r = torch.tensor(radius, dtype=torch.float32)
+    return d2 >= float(r * r)            # radius^2 as an fp32 product, like the kernel (gm3d_radius_mask_bits)
+
+
+def back_project(mask_coarse, idxs):
+    """Multi-scale masking: mask_coarse (B,G_last) bool (True = masked) -> [mask_0 .. mask_last]; a finer group is visible iff at
+    least one visible group of the next coarser level contains it.  Static shapes (integer scatter-add, no host sync)."""
+    masks = [mask_coarse]
+    for lvl in range(len(idxs) - 1, 0, -1):
+        idx = idxs[lvl]                                               # (B,G_l,k_l) members among the level l-1 groups
+        B, G_prev = idx.shape[0], idxs[lvl - 1].shape[1]
+        vis = (~masks[0]).unsqueeze(-1).expand_as(idx).reshape(B, -1).to(torch.int32)
+        cnt = torch.zeros(B, G_prev, dtype=torch.int32, device=idx.device).scatter_add_(1, idx.reshape(B, -1), vis)
+        masks.insert(0, cnt == 0)
+    return masks
+
+
+def _lin(x, conv, bn=None, act=False):
+    """Conv1d(k=1) (+ BatchNorm1d + ReLU) on a (rows, C) layout."""
+    y = F.linear(x, conv.weight.squeeze(-1), conv.bias)
+    if bn is not None:
+        y = bn(y)
+    return F.relu(y) if act else y
+
+
+class TokenEmbed(nn.Module):
+    """mini-PointNet of one level: (B,G,k,in_c) -> (B,G,out_c).  Level 0 reads xyz (the Point-MAE embed's layer sizes), deeper
+    levels read the previous level's token features."""
+
+    def __init__(self, in_c, out_c):
+        super().__init__()
+        a, b = (128, 256) if in_c == 3 else (in_c, in_c)
+        mid = 512 if in_c == 3 else out_c
+        self.first_conv = nn.Sequential(nn.Conv1d(in_c, a, 1), nn.BatchNorm1d(a), nn.ReLU(inplace=True), nn.Conv1d(a, b, 1))
+        self.second_conv = nn.Sequential(nn.Conv1d(2 * b, mid, 1), nn.BatchNorm1d(mid), nn.ReLU(inplace=True), nn.Conv1d(mid, out_c, 1))
+        self.out_c = out_c
+
+    def forward(self, groups):
+        B, G, k, C = groups.shape
+        x = groups.reshape(B * G * k, C)
+        f = _lin(_lin(x, self.first_conv[0], self.first_conv[1], True), self.first_conv[3])                  # (rows, b)
+        fg = f.view(B * G, k, -1).amax(dim=1, keepdim=True).expand(-1, k, -1)
+        y = torch.cat([fg, f.view(B * G, k, -1)], dim=-1).reshape(B * G * k, -1)
+        y = _lin(_lin(y, self.second_conv[0], self.second_conv[1], True), self.second_conv[3])
+        return y.view(B * G, k, self.out_c).amax(dim=1).view(B, G, self.out_c)
+
+
+class MaskedAttention(nn.Module):
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x, bits):
+        qkv = self.qkv(x)
+        hd = x.shape[-1] // self.num_heads
+        if bits is None and hd == 64 and x.shape[1] <= 128:
+            a = ops.attention(qkv, self.num_heads, self.scale)              # the Point-MAE kernel (whole head in one workgroup)
+        else:
+            a = ops.attention_masked(qkv, bits, self.num_heads, self.scale)
+        return self.proj(a)
+
+
+class MaskedBlock(nn.Module):
+    def __init__(self, dim, num_heads, drop_path=0.0):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = MaskedAttention(dim, num_heads)
+        self.drop_path = M.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = M.Mlp(in_features=dim, hidden_features=4 * dim)
+
+    def forward(self, x, bits=None):
+        x = x + self.drop_path(self.attn(self.norm1(x), bits))
+        return x + self.drop_path(self.mlp(self.norm2(x)))
+
+
+class BlockStack(nn.Module):
+    def __init__(self, dim, depth, num_heads, dpr):
+        super().__init__()
+        self.blocks = nn.ModuleList([MaskedBlock(dim, num_heads, dpr[i]) for i in range(depth)])
+
+    def forward(self, x, pos, bits=None):
+        for blk in self.blocks:                 # the position is re-added before every block, like Point-MAE
+            x = blk(x + pos, bits)
+        return x
+
+
+class TokenPropagation(nn.Module):
+    """Up-block of the hierarchical decoder: the coarse level's tokens interpolated to the fine centres (3 nearest coarse centres,
+    inverse squared-distance weights), concatenated with the fine level's own tokens, then a shared MLP."""
+
+    def __init__(self, in_channel, mlp):
+        super().__init__()
+        self.mlp_convs, self.mlp_bns = nn.ModuleList(), nn.ModuleList()
+        last = in_channel
+        for c in mlp:
+            self.mlp_convs.append(nn.Conv1d(last, c, 1))
+            self.mlp_bns.append(nn.BatchNorm1d(c))
+            last = c
+
+    def forward(self, xyz_fine, xyz_coarse, tok_fine, tok_coarse):
+        B, N, _ = xyz_fine.shape
+        with torch.no_grad():
+            dist, idx = ops.knn(xyz_coarse, xyz_fine, 3)                   # (B,N,3): Euclidean distances, ascending
+            w = 1.0 / (dist * dist + 1e-8)
+            w = w / w.sum(dim=-1, keepdim=True)
+        near = M.take(tok_coarse, idx.reshape(B, N * 3)).view(B, N, 3, -1)
+        interp = (near * w.unsqueeze(-1).to(near.dtype)).sum(dim=2)
+        y = torch.cat([tok_fine, interp.to(tok_fine.dtype)], dim=-1).reshape(B * N, -1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            y = _lin(y, conv, bn, True)
+        return y.view(B, N, -1)
+
+
+def _pos_mlp(dim):
+    return nn.Sequential(nn.Linear(3, dim), nn.GELU(), nn.Linear(dim, dim))
+
+
+class PointM2AE(nn.Module):
+    """config: the `model` section of cfgs/config_Point_M2AE.yaml (dict or attribute object)."""
+
+    def __init__(self, config=None):
+        super().__init__()
+        c = dict(mask_ratio=0.8, group_sizes=[16, 8, 8], num_groups=[512, 256, 64], encoder_depths=[5, 5, 5],
+                 encoder_dims=[96, 192, 384], local_radius=[0.32, 0.64, 1.28], decoder_depths=[1, 1], decoder_dims=[384, 192],
+                 decoder_up_blocks=[1, 1], drop_path_rate=0.1, num_heads=6)
+        if config is not None:
+            c.update({k: (config[k] if isinstance(config, dict) else getattr(config, k)) for k in c
+                      if (k in config if isinstance(config, dict) else hasattr(config, k))})
+        self.cfg = c
+        self.mask_ratio, self.num_heads = c["mask_ratio"], c["num_heads"]
+        self.num_group = c["num_groups"][-1]                                # the tokens GeoMask3D scores and masks
+        dims, depths = c["encoder_dims"], c["encoder_depths"]
+        assert len(dims) == 3 and c["decoder_dims"] == [dims[2], dims[1]], "built for the three-scale configuration"
+        self.local_radius = list(c["local_radius"])
+        self.group_divider = HierarchicalGroup(c["num_groups"], c["group_sizes"])
+        self.token_embed = nn.ModuleList([TokenEmbed(3 if i == 0 else dims[i - 1], dims[i]) for i in range(3)])
+        self.encoder_pos_embeds = nn.ModuleList([_pos_mlp(d) for d in dims])
+        dpr = [x.item() for x in torch.linspace(0, c["drop_path_rate"], sum(depths))]
+        self.encoder_blocks, at = nn.ModuleList(), 0
+        for d, n in zip(dims, depths):
+            self.encoder_blocks.append(BlockStack(d, n, self.num_heads, dpr[at:at + n]))
+            at += n
+        self.encoder_norms = nn.ModuleList([nn.LayerNorm(d) for d in dims])
+        ddims, ddepths = c["decoder_dims"], c["decoder_depths"]
+        ddpr = [x.item() for x in torch.linspace(0, c["drop_path_rate"], sum(ddepths))]
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, ddims[0]))
+        nn.init.trunc_normal_(self.mask_token, std=0.02)
+        self.decoder_pos_embeds = nn.ModuleList([_pos_mlp(d) for d in ddims])
+        self.h_decoder = nn.ModuleList([BlockStack(ddims[0], ddepths[0], self.num_heads, ddpr[:ddepths[0]]),
+                                        BlockStack(ddims[1], ddepths[1], self.num_heads, ddpr[ddepths[0]:])])
+        self.token_prop = nn.ModuleList([TokenPropagation(ddims[0] + ddims[1], [ddims[1] * 4, ddims[1]])])
+        self.decoder_norm = nn.LayerNorm(ddims[1])
+        self.rec_head = nn.Conv1d(ddims[1], 3 * c["group_sizes"][1], 1)
+        self.loss_pred_head = nn.Sequential(nn.Conv1d(ddims[0], 1024, 1), nn.BatchNorm1d(1024), nn.LeakyReLU(negative_slope=0.2),
+                                            nn.Conv1d(1024, ddims[0], 1))
+        self.loss_func = ops.ChamferDistanceL2()
+
+    # ------------------------------------------------------------------ forward
+    def encode(self, neighborhoods, centers, idxs, masks):
+        """-> per level: encoder outputs for every token position (only the visible ones are meaningful)."""
+        outs, prev = [], None
+        for i in range(3):
+            if i == 0:
+                tok = self.token_embed[0](neighborhoods[0])
+            else:
+                B, G, k = idxs[i].shape
+                tok = self.token_embed[i](M.take(prev, idxs[i].reshape(B, G * k)).view(B, G, k, -1))
+            vis = ~masks[i]
+            with torch.no_grad():       # == pack_mask(~(vis_i & vis_j) | radius_mask(centres)), one launch
+                bits = ops.radius_mask_bits(centers[i], vis, self.local_radius[i])
+            pos = self.encoder_pos_embeds[i](centers[i])
+            y = self.encoder_blocks[i](tok, pos.to(tok.dtype), bits)
+            outs.append(y)
+            prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
+        return outs
+
+    def forward(self, pts, mask=None, group=None, noaug=False):
+        """pts (B,N,3) f32; mask (B,64) bool over the COARSEST tokens (True = masked; None: nothing masked).
+        -> dict: rec (B,256,k1,3) reconstructed level-1 patches, loss_pred (B,64), masks (per level), group, features."""
+        neighborhoods, centers, idxs = group if group is not None else self.group_divider(pts)
+        B = centers[0].shape[0]
+        if mask is None:
+            mask = torch.zeros(B, self.num_group, dtype=torch.bool, device=centers[0].device)
+        masks = back_project(mask, idxs)
+        enc = self.encode(neighborhoods, centers, idxs, masks)
+        vis2, vis1 = ~masks[2], ~masks[1]
+        x2 = self.encoder_norms[2](enc[2])
+        if noaug:
+            return x2
+        xc = torch.where(vis2.unsqueeze(-1), x2, self.mask_token.to(x2.dtype).expand(B, self.num_group, -1))
+        xc = self.h_decoder[0](xc, self.decoder_pos_embeds[0](centers[2]).to(xc.dtype))
+        h = self.loss_pred_head
+        y = F.leaky_relu(h[1](F.linear(xc.reshape(B * self.num_group, -1), h[0].weight.squeeze(-1), h[0].bias)), h[2].negative_slope)
+        loss_pred = F.linear(y, h[3].weight.squeeze(-1), h[3].bias).mean(dim=-1).view(B, self.num_group)
+        x1 = self.encoder_norms[1](enc[1])
+        x1 = torch.where(vis1.unsqueeze(-1), x1, torch.zeros((), dtype=x1.dtype, device=x1.device))
+        x1 = self.token_prop[0](centers[1], centers[2], x1, xc)
+        x1 = self.h_decoder[1](x1, self.decoder_pos_embeds[1](centers[1]).to(x1.dtype))
+        x1 = self.decoder_norm(x1)
+        G1, k1 = neighborhoods[1].shape[1], neighborhoods[1].shape[2]
+        rec = F.linear(x1, self.rec_head.weight.squeeze(-1), self.rec_head.bias).view(B, G1, k1, 3)
+        return {"rec": rec, "loss_pred": loss_pred, "masks": masks, "group": (neighborhoods, centers, idxs), "features": x2}
+
+    def forward_loss(self, rec, neighborhoods, idxs, masks):
+        """Chamfer-L2 between the reconstructed and the true level-1 patches (k1 points each), averaged over the MASKED level-1
+        tokens; `matrix` (B,64): per coarsest token, the mean patch loss of its masked level-1 members (the loss predictor's
+        target)."""
+        B, G1, k1, _ = rec.shape
+        per_point = self.loss_func(rec.reshape(B * G1, k1, 3).float(), neighborhoods[1].reshape(B * G1, k1, 3).float())   # d1 + d2
+        cd = per_point.view(B, G1, k1).mean(dim=-1)                                   # (B,256)
+        m1 = masks[1].to(cd.dtype)
+        loss = (cd * m1).sum() / m1.sum().clamp_min(1.0)
+        member = idxs[2]                                                              # (B,64,k2) level-1 members of a coarse token
+        mm = M.take(m1, member.reshape(B, -1)).view(member.shape)
+        mc = M.take(cd, member.reshape(B, -1)).view(member.shape)
+        matrix = (mc * mm).sum(dim=-1) / mm.sum(dim=-1).clamp_min(1.0)
+        return {"Chamfer_mean": loss, "matrix": matrix, "per_token": cd}
+
+
+def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, group=None):
+    """One GeoMask3D iteration's forward on the hierarchical model: the EMA teacher scores the 64 coarsest tokens with nothing
+    masked, the guided mask (P/models_mae_learn_loss.py:744-784 with this model's mask ratio) hides the hardest ones, the student
+    reconstructs and predicts its own per-token loss.  -> dict with `loss`, `loss_chfr`, `loss_learn`, `mask`."""
+    raw = model.module if hasattr(model, "module") else model
+    with torch.no_grad():
+        group = group if group is not None else teacher.group_divider(pts)
+        t = teacher(pts, mask=None, group=group)
+        mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
+                                                      total_epoch=total_epoch, noise=mask_noise)
+        masked = mask.to(torch.bool)
+    out = model(pts, mask=masked, group=group)
+    lo = raw.forward_loss(out["rec"], group[0], group[2], out["masks"])
+    pred = M.take(out["loss_pred"].float(), mask_ids)
+    target = M.take(lo["matrix"].detach().float(), mask_ids)
+    from . import heads
+    loss_learn = heads.rank_loss(pred, target)
+    return {"loss": lo["Chamfer_mean"] + loss_learn, "loss_chfr": lo["Chamfer_mean"], "loss_learn": loss_learn, "mask": masked,
+            "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"]}
+
+
+def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None, augment=True):
+    """augment -> teacher -> mask -> student -> losses -> backward -> clip(5) -> AdamW -> EMA (the loop body of
+    P/engine_pretrain.py:77-212 around this model)."""
+    from . import engine_pretrain as E
+    from contextlib import nullcontext
+    if augment:
+        pts = E.train_transforms(pts)
+    amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
+    with amp:
+        out = pretrain_forward(model, model_ema.ema, pts, epoch, args.epochs, mask_noise=mask_noise)
+    optimizer.zero_grad(set_to_none=True)
+    out["loss"].backward()
+    out["grad_norm"] = E.step_update(model, model_ema, optimizer)
+    return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

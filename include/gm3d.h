@@ -355,6 +355,10 @@ int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
  * word j>>5 of row i set = query i must not attend to key j (NULL: no mask); the mask must be symmetric.  out (B,T,H*HD), lse
  * (B,H,T) f32 (0 for a query with no allowed key, whose output and gradients are zero).  dtype GM3D_BF16: flash-style MFMA
  * kernels; GM3D_F32: exact fp32 kernels (parity mode). */
+/* The bitset mask of one level of the hierarchical encoder: bits (B,G,ceil(G/32)), bit j of row i set iff token i or token j is
+ * not visible (vis (B,G) bytes, NULL = all visible) or their centres (B,G,3) are >= radius apart (radius <= 0: no radius test). */
+int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float radius, int B, int G, unsigned *bits,
+                          gm3d_stream_t stream);
 int gm3d_attention_masked_fwd(const void *qkv, const unsigned *mask, void *out, float *lse, int B, int T, int H, int HD, float scale,
                               int dtype, gm3d_stream_t stream);
 int gm3d_attention_masked_bwd(const void *qkv, const unsigned *mask, const void *out, const void *dout, const float *lse, void *dqkv,

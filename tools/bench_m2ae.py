@@ -1,0 +1,58 @@
+"""Point-M2AE + GeoMask3D pretrain step (BASELINE config #4: B=128 clouds of 2048 points, bf16) on 1 GPU: eager and hipGraph replay.
+    python tools/bench_m2ae.py [--batch 128] [--steps 20]   -> one JSON line"""
+import argparse, json, os, sys, time
+from types import SimpleNamespace
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gm3d_amd import engine_pretrain as E, point_m2ae as P
+from bench import make_clouds
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=128)
+ap.add_argument("--steps", type=int, default=20)
+ap.add_argument("--warmup", type=int, default=5)
+a = ap.parse_args()
+E.enable_tuned_gemms()
+torch.manual_seed(0)
+model = P.PointM2AE().cuda().train()
+ema = E.ModelEma(model, 0.999)
+opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
+args = SimpleNamespace(bf16=True, epochs=300)
+pool = [make_clouds(a.batch, 2048, 100 + i, "cuda") for i in range(4)]
+
+
+def run(step, n):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(n):
+        o = step(i)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n, o
+
+
+eager = lambda i: P.pretrain_step(model, ema, opt, pool[i % 4].clone(), 100, args)
+run(eager, a.warmup)
+t_eager, o = run(eager, a.steps)
+line = {"metric": "point-clouds/sec Point-M2AE+GM3D pretrain step (N=2048, G=512/256/64)", "unit": "clouds/s", "n_gpus": 1,
+        "dtype": "bf16", "data": "synthetic", "batch": a.batch, "eager_ms_per_step": t_eager * 1e3, "eager_clouds_per_s": a.batch / t_eager,
+        "loss": float(o["loss"])}
+try:
+    static_in = pool[0].clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = P.pretrain_step(model, ema, opt, static_in, 100, args)
+
+    def replay(i):
+        static_in.copy_(pool[i % 4])
+        g.replay()
+        return out
+    run(replay, a.warmup)
+    t_graph, o = run(replay, a.steps)
+    gl = float(o["loss"])
+    if gl != gl or abs(gl) == float("inf"):     # this model still runs PyTorch reductions that are not replay-safe on this stack
+        raise RuntimeError("replayed loss is not finite (torch multi-block reductions under replay: DESIGN 3c)")
+    line.update(graph_ms_per_step=t_graph * 1e3, value=a.batch / t_graph, ms_per_step=t_graph * 1e3, graph_loss=gl,
+                execution="hipGraph replay")
+except Exception as ex:
+    line.update(value=a.batch / t_eager, ms_per_step=t_eager * 1e3, execution="eager (capture failed: %s)" % str(ex)[:100])
+print(json.dumps(line))
