@@ -47,7 +47,7 @@ def algorithmic(name, meta):
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
     if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
-    if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMM (+ epilogues): 2*M*N*K flop
+    if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMMs (+ epilogues; register-prefetch and LDS-DMA ring forms): 2*M*N*K flop
         return "mfma", 2.0 * meta["M"] * meta["N"] * meta["K"], "FLOP"
     if name == "gm3d_gemm_nt_bf16":            # own weight-gradient GEMM, batched: 2*B*R*N*K flop (meta M = reduction rows)
         return "mfma", 2.0 * meta["B"] * meta["M"] * meta["N"] * meta["K"], "FLOP"

@@ -62,6 +62,7 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tile_rows": [_i],
+    "gm3d_gemm_tn_bf16_ring": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_transpose_bf16_batched": [_vp, _vp, _i, _i, _i, ctypes.c_longlong, _vp],
     "gm3d_token_assemble_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "gm3d_token_assemble_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],

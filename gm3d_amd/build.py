@@ -26,6 +26,7 @@ SOURCES = {
     "optim.hip": [],
     "gemm.hip": [],
     "gemm_nt.hip": [],
+    "gemm_ring.hip": [],
     "attention_masked.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

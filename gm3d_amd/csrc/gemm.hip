@@ -261,8 +261,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 static int gemm_tile_height(int M) {
     static const int forced = getenv("GM3D_GEMM_BM") ? atoi(getenv("GM3D_GEMM_BM")) : 0;
     if (forced == 64 || forced == 128) return forced;
-    static const int max64 = getenv("GM3D_GEMM_BM64_UPTO") ? atoi(getenv("GM3D_GEMM_BM64_UPTO")) : 4096;   // experiment knob
-    return M <= max64 ? 64 : 128;
+    return M <= 4096 ? 64 : 128;
 }
 
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,

@@ -1,0 +1,173 @@
+// C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]), bf16 in / fp32 accumulate / bf16 out -- the LONG-K, FEW-TILE members of the path's GEMM
+// family: fc2 (K = 1536 -> N = 384), the input gradients of fc1 (K = 1536) and qkv (K = 1152), at 3200 .. 8192 rows.
+//
+// Beneath: the same nn.Linear layers as csrc/gemm.hip (timm Block mlp.fc2 forward, mlp.fc1 / attn.qkv input gradients; in-tree twin
+// Point-MAE_SA3D/models/Point_MAE.py:82-125).
+//
+// Why a second kernel (MI355X).  With N = 384 a launch has only 3 column tiles: 150 .. 192 workgroups for 256 CUs, ONE per CU,
+// each walking 18 .. 24 K-stages.  A CU then has only its own loads in flight, and the register-prefetch pipeline of gemm.hip
+// (two stages = 48 KB) gets about half the ~70 GB/s a CU can pull from L2 (DESIGN 3b'): the tuned library wins 0.65x there.
+// This kernel keeps FOUR stages in an LDS ring filled by LDS-DMA (global_load_lds_dwordx4, no staging registers), two of them in
+// flight behind a counted s_waitcnt vmcnt, one raw s_barrier per stage.  The LDS image is the conflict-free 128-byte-row image of
+// csrc/attention.hip (16-byte chunk ch of row r at 128 r + 16 (ch ^ f(r))); LDS-DMA writes lane-linear, so the XOR is applied
+// to the per-lane SOURCE address.  MFMA loop and epilogue as in gemm.hip (transposed product: lanes = rows of C).
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 rbf16x8 __attribute__((ext_vector_type(8)));
+typedef float rf32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int RBN = 128, RBK = 64, RNBUF = 4, RCP = 132;
+
+__device__ __forceinline__ int ring_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int ring_off(int row, int ch) { return row * 128 + ((ch ^ ring_f(row)) << 4); }
+
+__device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// WMI: 32-row MFMA tiles per wave in M (1: 64-row workgroup tile, 2: 128-row)
+template <int WMI>
+__global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                           const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
+                                                           int lda, int ldw, int ldc, int tiles_n, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    constexpr int BM = 64 * WMI;
+    constexpr int STAGE = (BM + RBN) * 128;                 // bytes
+    constexpr int PA = BM / 8, PIECES = (PA + 16) / 4;      // 1-KiB pieces of the A tile; pieces per wave per stage (6 or 8)
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total_tiles) return;
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * RBN;
+    const int wm = (w >> 1) * 32 * WMI, wn = (w & 1) * 64;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)rsm;
+
+    // this lane's share of a stage: pieces p = w + 4 i (i < PIECES); piece p < PA: A rows 8p .. 8p+7, else W rows 8(p-PA) ..
+    const int prow = lane >> 3, pslot = lane & 7;
+    const bf16_t* src[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int p = w + 4 * i;
+        if (p < PA) {
+            const int row = 8 * p + prow;
+            const int am = m0 + row < M ? m0 + row : M - 1;          // rows past M: clamped (their outputs are never stored)
+            src[i] = A + (size_t)am * lda + ((pslot ^ ring_f(row)) << 3);
+        } else {
+            const int row = 8 * (p - PA) + prow;
+            src[i] = W + (size_t)(n0 + row) * ldw + ((pslot ^ ring_f(row)) << 3);
+        }
+    }
+#define GM3D_RING_STAGE(ST)                                                                          \
+    {                                                                                                \
+        const unsigned base = lds0 + ((ST) % RNBUF) * STAGE;                                         \
+        _Pragma("unroll") for (int i = 0; i < PIECES; ++i)                                           \
+            ring_glds16(src[i] + (size_t)(ST) * RBK, base + 1024 * (w + 4 * i));                     \
+    }
+
+    rf32x16 acc[WMI][2];
+#pragma unroll
+    for (int i = 0; i < WMI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+
+    const int KT = K / RBK;
+    GM3D_RING_STAGE(0)
+    if (KT > 1) GM3D_RING_STAGE(1)
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 2 < KT) {
+            GM3D_RING_STAGE(kt + 2)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+        } else if (kt + 1 < KT) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* as = rsm + (kt % RNBUF) * STAGE;
+        const unsigned char* ws = as + BM * 128;
+        rbf16x8 fa[4][WMI], fw[4][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < WMI; ++i) fa[s][i] = *reinterpret_cast<const rbf16x8*>(as + ring_off(wm + 32 * i + r, 2 * s + hh));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fw[s][j] = *reinterpret_cast<const rbf16x8*>(ws + ring_off(wn + 32 * j + r, 2 * s + hh));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < WMI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j], fa[s][i], acc[i][j], 0, 0, 0);
+    }
+#undef GM3D_RING_STAGE
+    __syncthreads();                 // every wave is done with the ring: it becomes the fp32 staging tile of the epilogue
+    float* cs = reinterpret_cast<float*>(rsm);
+#pragma unroll
+    for (int i = 0; i < WMI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = wm + 32 * i + r, n = wn + 32 * j + 8 * q + 4 * hh;
+                *reinterpret_cast<float4*>(cs + m * RCP + n) =
+                    make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4 * WMI; ++i) {
+        const int c = tid + 256 * i;
+        const int row = c >> 4, nc = (c & 15) * 8;
+        if (m0 + row < M) {
+            float v[8];
+            const float4 x = *reinterpret_cast<const float4*>(cs + row * RCP + nc), y = *reinterpret_cast<const float4*>(cs + row * RCP + nc + 4);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+            if (bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + nc), b1 = *reinterpret_cast<const float4*>(bias + n0 + nc + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+        }
+    }
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_gemm_tn_bf16_ring(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                                      int ldc, int bm, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!A || !W || !C || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (N % RBN || K % RBK || lda % 8 || ldw % 8 || ldc % 8 || lda < K || ldw < K || ldc < N) return GM3D_EUNSUPPORTED;
+    if ((((size_t)A | (size_t)W) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
+    if (M == 0) return GM3D_OK;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / RBN;
+    if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
+    const size_t lds = (size_t)RNBUF * (bm + RBN) * 128;
+#define GM3D_RING_LAUNCH(WMI)                                                                                             \
+    {                                                                                                                    \
+        static bool attr_done = false;                                                                                   \
+        if (!attr_done) {                                                                                                \
+            if (hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<WMI>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    (int)lds) != hipSuccess)                                                             \
+                return GM3D_ELAUNCH;                                                                                     \
+            attr_done = true;                                                                                            \
+        }                                                                                                                \
+        hipLaunchKernelGGL(gemm_tn_ring_kernel<WMI>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,  \
+                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total);                 \
+    }
+    if (bm == 64) GM3D_RING_LAUNCH(1) else GM3D_RING_LAUNCH(2)
+#undef GM3D_RING_LAUNCH
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

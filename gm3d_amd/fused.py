@@ -291,10 +291,8 @@ def block_params(block):
 
 
 def _mm(x, w):
-    """x (R,K) @ w (N,K)^T: the hand-written MFMA kernel on the shapes where it beats the tuned library solution."""
-    if gemm.supported(x, w) and gemm.prefer_own(x.shape[0], w.shape[0], w.shape[1]):
-        return gemm.linear_tn(x, w)
-    return x @ w.t()
+    """x (R,K) @ w (N,K)^T on the kernel gemm.choose names for the shape (hand-written register-prefetch / LDS-DMA ring / library)."""
+    return gemm.mm(x, w)
 
 
 class TransformerStackFn(torch.autograd.Function):
@@ -363,7 +361,7 @@ class TransformerStackFn(torch.autograd.Function):
                 yield
                 g = bias_gelu_fwd(f, b1, adt, g=GG[i] if need else None)
             yield
-            o = g @ weight_cache.get(w2, adt).t()
+            o = _mm(g, weight_cache.get(w2, adt))
             yield
             if need:
                 saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
@@ -440,7 +438,7 @@ class TransformerStackFn(torch.autograd.Function):
                                           partial=PLN[2 * i + 1])
             gi[5], gi[6], gi[4] = SLN[2 * i + 1, 0], SLN[2 * i + 1, 1], SLN[2 * i + 1, 2]
             # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
-            da = gemm.linear_tn(d_p, WPT[i]) if fuse_mlp_bwd else d_p @ weight_cache.get(wproj, adt)
+            da = gemm.mm(d_p, WPT[i]) if fuse_mlp_bwd else d_p @ weight_cache.get(wproj, adt)
             dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
             dh1 = dqkv @ weight_cache.get(wqkv, adt)
             G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,

@@ -1,6 +1,6 @@
 """bf16 GEMM of the block / mini-PointNet shapes on the hand-written MFMA kernel (csrc/gemm.hip): y = x @ w^T (+ bias), and
 its fused-epilogue forms (fc1+GELU, fc2-dgrad+GELU', conv+max-pool).  DESIGN.md 3b' has the design and the measurements;
-`prefer_own` lists the plain shapes where the kernel beats the tuned hipBLASLt solution (tools/gemm_kbench.py)."""
+`choose` names the kernel for every plain shape (table: tools/gemm_kbench.py -> profiles/r02_gemm_kbench.txt)."""
 import torch
 
 from ._capi import lib
@@ -33,6 +33,19 @@ def linear_tn(x, w, bias=None, out=None):
     return out
 
 
+def linear_tn_ring(x, w, bias=None, out=None, bm=None):
+    """linear_tn through the LDS-DMA ring kernel (csrc/gemm_ring.hip): same results bit for bit; for long K over few tiles."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    if bm is None:
+        bm = 64 if M <= 4096 else 128
+    _launch("gm3d_gemm_tn_bf16_ring", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ring, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N,
+            K, x.stride(0), w.stride(0), out.stride(0), int(bm), _stream())
+    return out
+
+
 def linear_gelu(x, w, bias, f_out=None, g_out=None):
     """fc1 -> GELU with the activation in the GEMM epilogue: g = GELU(x @ w^T + bias); `f_out` (optional) receives the
     bf16 pre-activation WITHOUT bias (what bias_gelu_bwd re-reads).  -> (f_out | None, g)."""
@@ -46,18 +59,34 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
     return f_out, g_out
 
 
-_PREFER = os.environ.get("GM3D_PREFER_OWN", "")
+def choose(M, N, K):
+    """Which kernel runs the plain product x (M,K) @ w (N,K)^T on MI355X: "lib" (hipBLASLt through torch.mm, TunableOp table),
+    "own" (register-prefetch kernel, csrc/gemm.hip), "ring64" / "ring128" (LDS-DMA ring, csrc/gemm_ring.hip, tile height).
+    From the per-shape table profiles/r02_gemm_kbench.txt (tools/gemm_kbench.py); rule: a shape stays on the library only where
+    the tuned library solution is >= 5 % faster than the best hand-written form."""
+    if (N, K) == (384, 384):
+        return "ring64" if M <= 4096 else "ring128"
+    if N == 384 and K in (1024, 1152, 1536):            # long K, three column tiles: the ring's regime
+        return "ring64" if M <= 4096 else "ring128"
+    if (N, K) == (1152, 384):
+        return "ring128" if M <= 3200 else "lib"
+    if (N, K) == (128, 256) and M >= 65536:
+        return "ring128"
+    return "lib"
 
 
-def prefer_own(M, N, K):
-    """Shapes where the hand-written kernel beats the tuned hipBLASLt solution on MI355X (tools/gemm_kbench.py)."""
-    if _PREFER == "all":          # experiment switches (GM3D_PREFER_OWN=all|none|small): see DESIGN 3b'
-        return True
-    if _PREFER == "none":
-        return False
-    if _PREFER == "small":        # every block-stack shape up to 4096 rows
-        return M <= 4096
-    return (N, K) == (384, 384) or ((N, K) == (1152, 384) and M <= 4096) or ((N, K) == (128, 256) and M >= 65536)
+def mm(x, w, bias=None, out=None):
+    """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names (the library when the operands do not meet the hand-written
+    kernels' layout rules)."""
+    how = choose(x.shape[0], w.shape[0], w.shape[1]) if supported(x, w) else "lib"
+    if how == "own":
+        return linear_tn(x, w, bias, out)
+    if how.startswith("ring"):
+        return linear_tn_ring(x, w, bias, out, bm=int(how[4:]))
+    y = x @ w.t()
+    if bias is not None:
+        y = y + bias.to(y.dtype)
+    return y if out is None else out.copy_(y)
 
 
 def linear_pool(x, w, bias, bias_after_pool, want_rows):

@@ -323,6 +323,11 @@ int gm3d_gemm_tn_bf16_pool(const void *A, const void *W, const float *bias, void
 int gm3d_gemm_tn_bf16_gelu_bwd(const void *dO, const void *Wt, const void *F, const float *bias, void *dF, float *colpart, int M,
                                int N, int K, int lda, int ldw, int ldf, int lddf, gm3d_stream_t stream);
 int gm3d_gemm_tile_rows(int M);
+/* The same product as gm3d_gemm_tn_bf16 (bit-identical results) through a four-stage LDS-DMA ring: for long K over few output
+ * tiles (fc2, the fc1 / qkv input gradients: N = 384, K = 1152 .. 1536), where one workgroup per CU has to keep more loads in
+ * flight than the register-prefetch kernel does.  bm = 64 or 128: tile height. */
+int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
+                           int bm, gm3d_stream_t stream);
 /* dst (batch, cols, rows) = transposes of `batch` row-major (rows, cols) bf16 matrices that start src_batch_stride elements apart
  * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 64. */
 int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows, int cols, long long src_batch_stride,

@@ -48,12 +48,19 @@ def run(rank, world, port, out, B=4, steps=3):
         seg = E.SegmentedDDPStep(m, ema, opt, args, data[0][ids].cuda(), 200, warmup_iters=0, augment=False,
                                  inject_mask_noise=True, use_graphs=(mode == "graph"))
         p_start = opt.P.clone()
-        # this rank's shard alone: the three segments without their collectives
+        # this rank's shard alone: the three segments without their collectives -- through the SAME executor as the step (the
+        # captured graphs in graph mode: an eager re-run may pick another library GEMM solution, i.e. other bf16 roundings)
         seg.static_noise.copy_(noise[0][ids].cuda())
-        seg._phase1(data[0][ids].cuda())
-        seg._phase2()
-        seg._phase3()
-        seg._cut1 = seg._cut2 = seg._cut3 = None
+        if mode == "graph":
+            seg.static_in.copy_(data[0][ids].cuda())
+            for k in range(3):
+                seg.graphs[k].replay()
+        else:
+            seg._phase1(data[0][ids].cuda())
+            seg._phase2()
+            seg._phase3()
+            seg._cut1 = seg._cut2 = seg._cut3 = None
+        torch.cuda.synchronize()
         g_local = opt.G.clone()
         losses, g_avg = [], None
         for i in range(steps):
@@ -68,7 +75,8 @@ def run(rank, world, port, out, B=4, steps=3):
         torch.cuda.synchronize()
         torch.save({"p_start": p_start.cpu(), "g_local": g_local.cpu(), "g_avg": g_avg.cpu(), "params": opt.P.cpu(),
                     "ema": opt.E.cpu(), "buf_pre": buf_pre.cpu(), "buf_post": bn.running_mean.cpu(), "losses": losses,
-                    "segments": {k: list(v) for k, v in opt.segment_ranges.items()}},
+                    "segments": {k: list(v) for k, v in opt.segment_ranges.items()},
+                    "names": [n for n, _ in opt._named], "offs": list(opt._offs)},
                    os.path.join(out, "%s_rank%d.pt" % (mode, rank)))
         del seg, opt, ema, m
         torch.cuda.empty_cache()

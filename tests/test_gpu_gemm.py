@@ -155,3 +155,24 @@ def test_gemm_nt_weight_gradient(nb, R, N, K):
         want2 = torch.bmm(dyv.float().transpose(1, 2), x.float())
         assert float((out - want2).abs().max()) <= 2e-5 * float(want2.abs().max()) * max(1.0, (R / 4096) ** 0.5)
         assert float(flat[:64].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 1536, 384), (3200, 1536, 384), (8192, 1152, 384), (8192, 384, 1152), (200, 64, 128),
+                                   (70, 128, 256), (3200, 384, 384)])
+@pytest.mark.parametrize("bm", [64, 128])
+def test_gemm_ring_equals_register_prefetch_kernel(M, K, N, bm):
+    """The LDS-DMA ring form (four stages in LDS, counted vmcnt, source-side swizzle) multiplies in the same order as the
+    register-prefetch kernel: results bit-identical, with and without bias, rows past M untouched."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + bm)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias in (None, b):
+        want = gemm.linear_tn(x, w, bias)
+        out = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn_ring(x, w, bias, out=out[:M], bm=bm)
+        assert torch.equal(out[:M], want)
+        assert bool((out[M:] == 7.0).all())
+    ref = x.float() @ w.float().t()
+    assert float((want.float() - (ref + b)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2

@@ -7,7 +7,7 @@ from gm3d_amd import gemm, engine_pretrain as E
 
 E.enable_tuned_gemms()
 dev = torch.device("cuda")
-SHAPES = [(8192, 384, 1152), (8192, 384, 384), (8192, 384, 1536), (8192, 1536, 384), (8192, 1152, 384),
+SHAPES = [(4096, 384, 1152), (4096, 384, 384), (4096, 384, 1536), (4096, 1536, 384), (4096, 1152, 384), (8192, 384, 1152), (8192, 384, 384), (8192, 384, 1536), (8192, 1536, 384), (8192, 1152, 384),
           (3200, 384, 1152), (3200, 384, 384), (3200, 384, 1536), (3200, 1536, 384), (3200, 1152, 384),
           (262144, 128, 256), (262144, 256, 512), (262144, 512, 384), (262144, 384, 512), (262144, 512, 256), (262144, 256, 128),
           (8192, 384, 1024), (8192, 1024, 384)]
@@ -38,6 +38,8 @@ for M, K, N in SHAPES:
              torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for _ in range(nset)]
     t_lib = train(lambda x, w, o: torch.mm(x, w.t(), out=o), sets)
     t_own = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
+    t_r64 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=64), sets)
+    t_r128 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=128), sets)
     fl = 2.0 * M * K * N
-    print("M=%6d K=%4d N=%4d   hipBLASLt %7.1f us %5.0f TF/s   own %7.1f us %5.0f TF/s   x%.2f" %
-          (M, K, N, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_lib / t_own))
+    print("M=%6d K=%4d N=%4d   hipBLASLt %7.1f us %5.0f TF/s   own %7.1f us %5.0f TF/s x%.2f   ring64 %7.1f us x%.2f   ring128 %7.1f us x%.2f" %
+          (M, K, N, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_lib / t_own, t_r64, t_lib / t_r64, t_r128, t_lib / t_r128))
