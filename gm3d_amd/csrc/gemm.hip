@@ -27,14 +27,23 @@ constexpr int GSTAGE = (GBM + GBN) * GPITCH;   // bf16 elements per stage
 // KTT: K / 64 when it is one of the path's values (fully unrolled: exact s_waitcnt counts), 0 = run-time loop.
 // WMI: 32-row MFMA tiles per wave in M -- 2: 128x128 workgroup tile; 1: 64x128 (the 3200-row token streams, where 128-row tiles
 // leave 40 % of the workgroup slots empty)
-template <int KTT, int WMI>
+// LNA: the A operand is LayerNorm(U) of an fp32 residual stream U (M x 384) whose per-row statistics arrive as three (mean, sum of
+// squared deviations) pairs over 128-column tiles (written by gm3d_gemm_tn_bf16_res): every thread combines the pairs of its rows
+// once (Chan's formula), then normalises, scales and shifts each 8-element chunk in registers on its way from global memory to
+// the LDS stage -- models_mae_learn_loss.py's norm1 / norm2 (timm Block, Point-MAE_SA3D/models/Point_MAE.py:128-146) without a pass of
+// their own.  The workgroups of column tile 0 also write the normalised rows (bf16, the weight-gradient GEMM's operand) and the
+// row mean / rstd (the LayerNorm backward's inputs) when asked to.
+template <int KTT, int WMI, bool LNA>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ C, int M,
                                                               int N, int K, int lda, int ldw, int ldc, int tiles_n,
                                                               int total_tiles, bf16_t* __restrict__ G, int ldg,
                                                               bf16_t* __restrict__ P, uint8_t* __restrict__ ARG, int ldp,
                                                               int bias_after_pool, const bf16_t* __restrict__ Fpre, int ldfp,
-                                                              float* __restrict__ colpart) {
+                                                              float* __restrict__ colpart, const float* __restrict__ Af,
+                                                              const float* __restrict__ lnstats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps, bf16_t* __restrict__ Hout,
+                                                              float* __restrict__ mean_out, float* __restrict__ rstd_out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char gsm[];
     bf16_t* sm = reinterpret_cast<bf16_t*>(gsm);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -54,7 +63,9 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     // global -> register prefetch, TWO stages deep: 4 chunks of A and 4 of W per thread per stage (16 bytes each), two register
     // sets.  Iteration kt issues the loads of stage kt+2, multiplies stage kt, and only then parks stage kt+1 (issued one
     // iteration ago) in the LDS buffer that stage kt-1 vacated: a load has a whole iteration plus a multiply to arrive.
-    gbf16x8 pa[2][ACH], pw[2][4];
+    gbf16x8 pa[2][LNA ? 1 : ACH], pw[2][4];
+    float4 paf[2][LNA ? ACH : 1][2], pg[2][2], pb[2][2];      // LNA: fp32 chunks of U, and the gamma / beta chunk of the stage
+    float mu[ACH], rsd[ACH];
     const int crow = tid >> 3, ckc = (tid & 7) * 8;           // chunk c = tid + 256*i -> row = crow + 32*i, k offset ckc
     size_t aoff[ACH], woff[4];
 #pragma unroll
@@ -65,21 +76,66 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
         if (i < ACH) {
             const int am = m0 + row < M ? m0 + row : M - 1;
             aoff[i] = (size_t)am * lda + ckc;
+            if (LNA) {
+                // statistics of the 384-wide row from its three 128-wide tiles: mean of means, M2 = sum M2_t + 128 sum (m_t - m)^2
+                const float m0_ = lnstats[((size_t)0 * M + am) * 2], q0 = lnstats[((size_t)0 * M + am) * 2 + 1];
+                const float m1_ = lnstats[((size_t)1 * M + am) * 2], q1 = lnstats[((size_t)1 * M + am) * 2 + 1];
+                const float m2_ = lnstats[((size_t)2 * M + am) * 2], q2 = lnstats[((size_t)2 * M + am) * 2 + 1];
+                const float mean = (m0_ + m1_ + m2_) * (1.0f / 3.0f);
+                const float d0 = m0_ - mean, d1 = m1_ - mean, d2 = m2_ - mean;
+                const float m2sum = (q0 + q1 + q2) + 128.0f * (d0 * d0 + d1 * d1 + d2 * d2);
+                mu[i] = mean;
+                rsd[i] = rsqrtf(m2sum * (1.0f / 384.0f) + eps);
+                if (mean_out && tile_n == 0 && (tid & 7) == 0 && m0 + row < M) {
+                    mean_out[am] = mean;
+                    rstd_out[am] = rsd[i];
+                }
+            }
         }
         woff[i] = (size_t)(n0 + row) * ldw + ckc;
     }
 #define GM3D_LOAD_STAGE(SET, K0)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-        if (i < ACH) pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));  \
+        if (LNA) {                                                                        \
+            if (i < ACH) {                                                                \
+                paf[SET][LNA ? i : 0][0] = *reinterpret_cast<const float4*>(Af + aoff[i] + (K0));      \
+                paf[SET][LNA ? i : 0][1] = *reinterpret_cast<const float4*>(Af + aoff[i] + (K0) + 4);  \
+            }                                                                             \
+        } else if (i < ACH) pa[SET][LNA ? 0 : i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0)); \
         pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + (K0));               \
+    }                                                                                     \
+    if (LNA) {                                                                            \
+        pg[SET][0] = *reinterpret_cast<const float4*>(gamma + ckc + (K0));                \
+        pg[SET][1] = *reinterpret_cast<const float4*>(gamma + ckc + (K0) + 4);            \
+        pb[SET][0] = *reinterpret_cast<const float4*>(beta + ckc + (K0));                 \
+        pb[SET][1] = *reinterpret_cast<const float4*>(beta + ckc + (K0) + 4);             \
     }
-#define GM3D_STORE_STAGE(SET, ST)                                                         \
+#define GM3D_STORE_STAGE(SET, ST, K0)                                                     \
     {                                                                                     \
         bf16_t* as_ = sm + (ST) * STAGE;                                                  \
         bf16_t* ws_ = as_ + BM * GPITCH;                                                  \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                   \
             const int row = crow + 32 * i;                                                \
-            if (i < ACH) *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i]; \
+            if (i < ACH) {                                                                \
+                if (LNA) {                                                                \
+                    const float4 x0 = paf[SET][LNA ? i : 0][0], x1 = paf[SET][LNA ? i : 0][1];            \
+                    const float4 g0 = pg[SET][0], g1 = pg[SET][1], b0 = pb[SET][0], b1 = pb[SET][1];      \
+                    const float m_ = mu[i], r_ = rsd[i];                                  \
+                    gbf16x8 hv;                                                           \
+                    hv[0] = (bf16_t)((x0.x - m_) * r_ * g0.x + b0.x);                     \
+                    hv[1] = (bf16_t)((x0.y - m_) * r_ * g0.y + b0.y);                     \
+                    hv[2] = (bf16_t)((x0.z - m_) * r_ * g0.z + b0.z);                     \
+                    hv[3] = (bf16_t)((x0.w - m_) * r_ * g0.w + b0.w);                     \
+                    hv[4] = (bf16_t)((x1.x - m_) * r_ * g1.x + b1.x);                     \
+                    hv[5] = (bf16_t)((x1.y - m_) * r_ * g1.y + b1.y);                     \
+                    hv[6] = (bf16_t)((x1.z - m_) * r_ * g1.z + b1.z);                     \
+                    hv[7] = (bf16_t)((x1.w - m_) * r_ * g1.w + b1.w);                     \
+                    *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = hv;           \
+                    if (Hout && tile_n == 0 && m0 + row < M)                              \
+                        *reinterpret_cast<gbf16x8*>(Hout + (size_t)(m0 + row) * K + (K0) + ckc) = hv;     \
+                } else                                                                    \
+                    *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][LNA ? 0 : i];         \
+            }                                                                             \
             *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];           \
         }                                                                                 \
     }
@@ -95,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     const int KT = KTT > 0 ? KTT : K / GBK;
     GM3D_LOAD_STAGE(0, 0)
     if (KT > 1) GM3D_LOAD_STAGE(1, GBK)
-    GM3D_STORE_STAGE(0, 0)
+    GM3D_STORE_STAGE(0, 0, 0)
     __syncthreads();
     // the loop is unrolled by two so that register-set indices are compile-time constants; with a compile-time KT it is
     // fully unrolled, which lets the compiler count outstanding loads exactly (vmcnt(8): stage kt+2 stays in flight while
@@ -123,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
             _Pragma("unroll") for (int i = 0; i < WMI; ++i)                                                                \
                 _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                              \
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s][j], fa[s][i], acc[i][j], 0, 0, 0);           \
-        if ((KT_) + 1 < KT) GM3D_STORE_STAGE(NXT, NXT)          /* stage KT_+1 (register set NXT) -> LDS buffer NXT */     \
+        if ((KT_) + 1 < KT) GM3D_STORE_STAGE(NXT, NXT, ((KT_) + 1) * GBK)   /* stage KT_+1 (register set NXT) -> LDS buffer NXT */ \
         __syncthreads();                                                                                                   \
     }
         GM3D_ITER(kt, 0, 1)
@@ -264,33 +320,51 @@ static int gemm_tile_height(int M) {
     return M <= 4096 ? 64 : 128;
 }
 
+struct GemmLn {      // LayerNorm-on-load arguments (gm3d_gemm_tn_bf16_lna*)
+    const float* U = nullptr; const float* stats = nullptr; const float* gamma = nullptr; const float* beta = nullptr; float eps = 0.f;
+    void* H = nullptr; float* mean = nullptr; float* rstd = nullptr;
+};
+
 static int gemm_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc,
                        void* G, int ldg, gm3d_stream_t stream, void* P = nullptr, uint8_t* ARG = nullptr, int ldp = 0,
-                       int bias_after_pool = 0, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr) {
+                       int bias_after_pool = 0, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr,
+                       const GemmLn* ln = nullptr) {
     using namespace gm3d;
+    if (ln) {
+        if (!ln->U || !ln->stats || !ln->gamma || !ln->beta || K != 384 || lda % 4 || (ln->mean && !ln->rstd)) return GM3D_EINVAL;
+        A = ln->U;      // only checked for null / alignment below; the kernel reads ln->U
+    }
     if (!A || !W || (!C && !G && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp < N)) return GM3D_EINVAL;
     if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
     if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int bm = gemm_tile_height(M);
+    const int bm = ln ? 64 : gemm_tile_height(M);     // LayerNorm-on-load: 64-row tiles (the 128-row form would spill its fp32 staging registers)
     const int tiles_m = (M + bm - 1) / bm, tiles_n = N / GBN;
     if ((long long)tiles_m * tiles_n > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
     const size_t lds_ab = (size_t)2 * (bm + GBN) * GPITCH * sizeof(bf16_t), lds_c = (size_t)bm * GCP * sizeof(float);
     const size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
-#define GM3D_GEMM_LAUNCH(KTT, WMI)                                                                                             \
+#define GM3D_GEMM_LAUNCH_(KTT, WMI, LNA)                                                                                       \
     {                                                                                                                         \
         static bool attr_done = false;                                                                                        \
         if (!attr_done) {                                                                                                     \
-            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT, WMI>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT, WMI, LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds) != hipSuccess)                                                                  \
                 return GM3D_ELAUNCH;                                                                                          \
             attr_done = true;                                                                                                 \
         }                                                                                                                     \
-        hipLaunchKernelGGL((gemm_tn_bf16_kernel<KTT, WMI>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg,      \
-                           (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart);                        \
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<KTT, WMI, LNA>), dim3(grid), dim3(256), lds, (hipStream_t)stream,             \
+                           (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total,      \
+                           (bf16_t*)G, ldg, (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart,        \
+                           ln ? ln->U : nullptr, ln ? ln->stats : nullptr, ln ? ln->gamma : nullptr, ln ? ln->beta : nullptr,  \
+                           ln ? ln->eps : 0.f, ln ? (bf16_t*)ln->H : nullptr, ln ? ln->mean : nullptr, ln ? ln->rstd : nullptr); \
+    }
+#define GM3D_GEMM_LAUNCH(KTT, WMI) GM3D_GEMM_LAUNCH_(KTT, WMI, false)
+    if (ln) {       // K = 384: six stages
+        GM3D_GEMM_LAUNCH_(6, 1, true)
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
     }
 #define GM3D_GEMM_CASE(KTT)                                                                                                   \
     case KTT:                                                                                                                 \
@@ -303,6 +377,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
             if (bm == 64) GM3D_GEMM_LAUNCH(0, 1) else GM3D_GEMM_LAUNCH(0, 2)
     }
 #undef GM3D_GEMM_LAUNCH
+#undef GM3D_GEMM_LAUNCH_
 #undef GM3D_GEMM_CASE
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
@@ -330,6 +405,15 @@ extern "C" int gm3d_gemm_tn_bf16_gelu_bwd(const void* dO, const void* Wt, const 
                                           int M, int N, int K, int lda, int ldw, int ldf, int lddf, gm3d_stream_t stream) {
     if (!F || !bias || !dF || !colpart || ldf % 8 || ldf < N) return GM3D_EINVAL;
     return gemm_launch(dO, Wt, bias, dF, M, N, K, lda, ldw, lddf, nullptr, 0, stream, nullptr, nullptr, 0, 0, F, ldf, colpart);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_lna(const float* U, const float* stats, const float* gamma, const float* beta, float eps, const void* W,
+                                     const float* bias, void* C, void* G, void* H, float* mean, float* rstd, int M, int N, int K, int ldu,
+                                     int ldw, int ldc, int ldg, gm3d_stream_t stream) {
+    GemmLn ln;
+    ln.U = U; ln.stats = stats; ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.H = H; ln.mean = mean; ln.rstd = rstd;
+    if (G && !bias) return GM3D_EINVAL;
+    return gemm_launch(U, W, bias, C, M, N, K, ldu, ldw, ldc, G, ldg, stream, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, &ln);
 }
 
 extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gemm_tile_height(M) - 1) / gemm_tile_height(M); }

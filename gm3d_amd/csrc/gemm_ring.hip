@@ -32,10 +32,18 @@ __device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned dst) {
 }
 
 // WMI: 32-row MFMA tiles per wave in M (1: 64-row workgroup tile, 2: 128-row)
-template <int WMI>
+// RES: residual epilogue of a transformer block's proj / fc2 (N = 384 = the LayerNorm width): instead of C the kernel writes the
+//   fp32 residual stream  U = res + rowscale[row / rows_per_sample] * (A.W^T + bias) (+ add)   -- what gm3d_residual_ln_fwd
+//   computes before it normalises -- and, per row and 128-column tile, the (mean, sum of squared deviations) of those 128
+//   values: stats[tile_n][row][2].  The LayerNorm itself is applied by the consumer GEMM while it stages its A operand
+//   (gm3d_gemm_tn_bf16_lna), so the normalised rows never make an HBM round trip of their own.
+template <int WMI, bool RES>
 __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
-                                                           int lda, int ldw, int ldc, int tiles_n, int total_tiles) {
+                                                           int lda, int ldw, int ldc, int tiles_n, int total_tiles,
+                                                           const float* __restrict__ res, const float* __restrict__ rowscale,
+                                                           int rows_per_sample, const bf16_t* __restrict__ add, float* __restrict__ U,
+                                                           float* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     constexpr int BM = 64 * WMI;
     constexpr int STAGE = (BM + RBN) * 128;                 // bytes
@@ -124,6 +132,52 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
                     make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
             }
     __syncthreads();
+    if (RES) {
+#pragma unroll
+        for (int i = 0; i < 4 * WMI; ++i) {
+            const int c = tid + 256 * i;
+            const int row = c >> 4, nc = (c & 15) * 8;          // the 16 lanes that hold one row's 128 columns are neighbours
+            const bool valid = m0 + row < M;
+            const int gr = valid ? m0 + row : M - 1;
+            float v[8], rv[8];
+            const float4 x = *reinterpret_cast<const float4*>(cs + row * RCP + nc), y = *reinterpret_cast<const float4*>(cs + row * RCP + nc + 4);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+            // the product enters the residual stream rounded to bf16, exactly like the stored product of the two-kernel path
+            // (GEMM -> gm3d_residual_ln_fwd): u = res + rowscale * (bf16(acc) + bias) + add
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (float)(bf16_t)v[e];
+            if (bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + nc), b1 = *reinterpret_cast<const float4*>(bias + n0 + nc + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            const float rs = rowscale ? rowscale[gr / rows_per_sample] : 1.0f;
+            V8<float>::load(res + (size_t)gr * N + n0 + nc, rv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = rv[e] + rs * v[e];
+            if (add) {
+                float av[8];
+                V8<bf16_t>::load(add + (size_t)gr * N + n0 + nc, av);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += av[e];
+            }
+            if (valid) V8<float>::store(U + (size_t)gr * N + n0 + nc, v);
+            float sm = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm += v[e];
+            sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2); sm += __shfl_xor(sm, 4); sm += __shfl_xor(sm, 8);
+            const float mu = sm * (1.0f / 128.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = v[e] - mu; q += d * d; }
+            q += __shfl_xor(q, 1); q += __shfl_xor(q, 2); q += __shfl_xor(q, 4); q += __shfl_xor(q, 8);
+            if (valid && (c & 15) == 0) {
+                float* sp = stats + ((size_t)tile_n * M + gr) * 2;
+                sp[0] = mu;
+                sp[1] = q;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4 * WMI; ++i) {
         const int c = tid + 256 * i;
@@ -143,31 +197,50 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
 
 }  // namespace gm3d
 
-extern "C" int gm3d_gemm_tn_bf16_ring(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
-                                      int ldc, int bm, gm3d_stream_t stream) {
+static int ring_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc, int bm,
+                       gm3d_stream_t stream, const float* res, const float* rowscale, int rows_per_sample, const void* add, float* U,
+                       float* stats) {
     using namespace gm3d;
-    if (!A || !W || !C || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
-    if (N % RBN || K % RBK || lda % 8 || ldw % 8 || ldc % 8 || lda < K || ldw < K || ldc < N) return GM3D_EUNSUPPORTED;
+    if (!A || !W || (!C && !U) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (N % RBN || K % RBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
     if ((((size_t)A | (size_t)W) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
     const int tiles_m = (M + bm - 1) / bm, tiles_n = N / RBN;
     if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
     const size_t lds = (size_t)RNBUF * (bm + RBN) * 128;
-#define GM3D_RING_LAUNCH(WMI)                                                                                             \
+#define GM3D_RING_LAUNCH(WMI, RES)                                                                                        \
     {                                                                                                                    \
         static bool attr_done = false;                                                                                   \
         if (!attr_done) {                                                                                                \
-            if (hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<WMI>, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+            if (hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<WMI, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                     (int)lds) != hipSuccess)                                                             \
                 return GM3D_ELAUNCH;                                                                                     \
             attr_done = true;                                                                                            \
         }                                                                                                                \
-        hipLaunchKernelGGL(gemm_tn_ring_kernel<WMI>, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A,  \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total);                 \
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<WMI, RES>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
+                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, res, rowscale,    \
+                           rows_per_sample, (const bf16_t*)add, U, stats);                                               \
     }
-    if (bm == 64) GM3D_RING_LAUNCH(1) else GM3D_RING_LAUNCH(2)
+    if (U) {
+        if (bm == 64) GM3D_RING_LAUNCH(1, true) else GM3D_RING_LAUNCH(2, true)
+    } else {
+        if (bm == 64) GM3D_RING_LAUNCH(1, false) else GM3D_RING_LAUNCH(2, false)
+    }
 #undef GM3D_RING_LAUNCH
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
+}
+
+extern "C" int gm3d_gemm_tn_bf16_ring(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                                      int ldc, int bm, gm3d_stream_t stream) {
+    if (!C) return GM3D_EINVAL;
+    return ring_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, bm, stream, nullptr, nullptr, 1, nullptr, nullptr, nullptr);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_res(const void* A, const void* W, const float* bias, const float* res, const float* rowscale,
+                                     int rows_per_sample, const void* add, float* U, float* stats, int M, int N, int K, int lda,
+                                     int ldw, int bm, gm3d_stream_t stream) {
+    if (!res || !U || !stats || N != 384 || (rowscale && rows_per_sample < 1)) return GM3D_EINVAL;
+    return ring_launch(A, W, bias, nullptr, M, N, K, lda, ldw, 0, bm, stream, res, rowscale, rows_per_sample, add, U, stats);
 }

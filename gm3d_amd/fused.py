@@ -338,9 +338,43 @@ class TransformerStackFn(torch.autograd.Function):
             A = torch.empty(nblk, R, C, dtype=adt, device=dev)
             H2 = torch.empty(nblk, R, C, dtype=adt, device=dev)
             GG = torch.empty(nblk, R, 4 * C, dtype=adt, device=dev)
+        # LayerNorm folded into the GEMMs around it (bf16 path): proj / fc2 write the fp32 residual stream + per-tile row
+        # statistics in their epilogue (gm3d_gemm_tn_bf16_res), qkv / fc1 normalise while they stage their A operand
+        # (gm3d_gemm_tn_bf16_lna).  Stand-alone LayerNorm passes remain only in front of the first block and behind the last.
+        fuse_ln = (gemm.ENABLED and gemm.FUSE_LN and gemm.FUSE_GELU and adt == torch.bfloat16 and x.is_cuda
+                   and all(gemm.supported(posa, weight_cache.get(params[i * PER_BLOCK + k], adt)) or k == 9
+                           for i in range(nblk) for k in (2, 3, 7)))
+        st1 = None
         for i in range(nblk):
             ln1w, ln1b, wqkv, wproj, bproj, ln2w, ln2b, w1, b1, w2, b2 = params[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             dp1, dp2 = meta["dp"][i]
+            if fuse_ln:
+                if i == 0:
+                    u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
+                    yield
+                    qkv = _mm(h1, weight_cache.get(wqkv, adt))
+                else:       # u, st1: the previous block's fc2 epilogue
+                    qkv, m1, r1 = gemm.linear_lna(u, st1, ln1w, ln1b, eps, weight_cache.get(wqkv, adt), None,
+                                                  h_out=H1[i] if need else None, want_stats=need)
+                yield
+                a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
+                yield
+                x1, st2 = gemm.linear_res(a, weight_cache.get(wproj, adt), bproj, u, dp1, T, None)
+                yield
+                W1 = weight_cache.get(w1, adt)
+                f, g, m2, r2 = gemm.linear_lna(x1, st2, ln2w, ln2b, eps, W1, b1, gelu=True,
+                                               f_out=torch.empty(R, W1.shape[0], dtype=adt, device=dev) if need else None,
+                                               g_out=GG[i] if need else None, h_out=H2[i] if need else None, want_stats=need)
+                yield
+                if need:
+                    saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
+                if i + 1 < nblk:
+                    u, st1 = gemm.linear_res(g, weight_cache.get(w2, adt), b2, x1, dp2, T, posa)
+                else:
+                    o = _mm(g, weight_cache.get(w2, adt))
+                    res, y, bias, rs = x1, o, b2, dp2
+                yield
+                continue
             u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
             yield
             qkv = _mm(h1, weight_cache.get(wqkv, adt))

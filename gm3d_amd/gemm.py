@@ -46,6 +46,45 @@ def linear_tn_ring(x, w, bias=None, out=None, bm=None):
     return out
 
 
+FUSE_LN = os.environ.get("GM3D_FUSE_LN", "1") == "1"     # LayerNorm folded into the producer / consumer GEMMs (fused.py)
+
+
+def linear_res(x, w, bias, res, rowscale, rows_per_sample, add, bm=None):
+    """proj / fc2 with the residual epilogue: -> (U (M,384) f32 = res + rowscale * (bf16(x @ w^T) + bias) + add, stats (3,M,2) f32)."""
+    M, K = x.shape
+    N = w.shape[0]
+    U = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    stats = torch.empty(3, M, 2, dtype=torch.float32, device=x.device)
+    if bm is None:
+        bm = 64 if M <= 4096 else 128
+    _launch("gm3d_gemm_tn_bf16_res", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_res, _ptr(x), _ptr(w), _ptr(bias), _ptr(res),
+            _ptr(rowscale), int(rows_per_sample), _ptr(add), _ptr(U), _ptr(stats), M, N, K, x.stride(0), w.stride(0), int(bm), _stream())
+    return U, stats
+
+
+def linear_lna(U, stats, gamma, beta, eps, w, bias=None, gelu=False, f_out=None, g_out=None, h_out=None, want_stats=False):
+    """LayerNorm(U) @ w^T (+ bias) with the normalisation applied while the A operand is staged.
+    gelu=False -> (C (M,N) bf16, mean, rstd); gelu=True -> (f_out | None, G = GELU(.. + bias), mean, rstd).  h_out (M,384) bf16
+    receives the normalised rows, mean / rstd (M) f32 are produced when want_stats."""
+    M, K = U.shape
+    N = w.shape[0]
+    dev = U.device
+    mean = torch.empty(M, dtype=torch.float32, device=dev) if want_stats else None
+    rstd = torch.empty(M, dtype=torch.float32, device=dev) if want_stats else None
+    if gelu:
+        if g_out is None:
+            g_out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        _launch("gm3d_gemm_tn_bf16_lna", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_lna, _ptr(U), _ptr(stats), _ptr(gamma),
+                _ptr(beta), float(eps), _ptr(w), _ptr(bias), _ptr(f_out), _ptr(g_out), _ptr(h_out), _ptr(mean), _ptr(rstd), M, N, K,
+                U.stride(0), w.stride(0), f_out.stride(0) if f_out is not None else 0, g_out.stride(0), _stream())
+        return f_out, g_out, mean, rstd
+    c = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    _launch("gm3d_gemm_tn_bf16_lna", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_lna, _ptr(U), _ptr(stats), _ptr(gamma), _ptr(beta),
+            float(eps), _ptr(w), _ptr(bias), _ptr(c), None, _ptr(h_out), _ptr(mean), _ptr(rstd), M, N, K, U.stride(0), w.stride(0),
+            c.stride(0), 0, _stream())
+    return c, mean, rstd
+
+
 def linear_gelu(x, w, bias, f_out=None, g_out=None):
     """fc1 -> GELU with the activation in the GEMM epilogue: g = GELU(x @ w^T + bias); `f_out` (optional) receives the
     bf16 pre-activation WITHOUT bias (what bias_gelu_bwd re-reads).  -> (f_out | None, g)."""
