@@ -61,7 +61,7 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
-    "gm3d_gemm_tn_bf16_res": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_res": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_lna": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tile_rows": [_i],
     "gm3d_gemm_tn_bf16_ring": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -27,10 +27,10 @@ constexpr int GSTAGE = (GBM + GBN) * GPITCH;   // bf16 elements per stage
 // KTT: K / 64 when it is one of the path's values (fully unrolled: exact s_waitcnt counts), 0 = run-time loop.
 // WMI: 32-row MFMA tiles per wave in M -- 2: 128x128 workgroup tile; 1: 64x128 (the 3200-row token streams, where 128-row tiles
 // leave 40 % of the workgroup slots empty)
-// LNA: the A operand is LayerNorm(U) of an fp32 residual stream U (M x 384) whose per-row statistics arrive as three (mean, sum of
-// squared deviations) pairs over 128-column tiles (written by gm3d_gemm_tn_bf16_res): every thread combines the pairs of its rows
-// once (Chan's formula), then normalises, scales and shifts each 8-element chunk in registers on its way from global memory to
-// the LDS stage -- models_mae_learn_loss.py's norm1 / norm2 (timm Block, Point-MAE_SA3D/models/Point_MAE.py:128-146) without a pass of
+// LNA: the A operand is LayerNorm(U) of the residual stream U (M x 384), read from the bf16 copy U16 the producer wrote beside the
+// fp32 stream; the per-row statistics (exact, from the fp32 values) arrive as three (mean, sum of squared deviations) pairs over
+// 128-column tiles (gm3d_gemm_tn_bf16_res): every thread combines the pairs of its rows once (Chan's formula), then normalises,
+// scales and shifts each 8-element chunk in registers on its way from global memory to the LDS stage -- models_mae_learn_loss.py's norm1 / norm2 (timm Block, Point-MAE_SA3D/models/Point_MAE.py:128-146) without a pass of
 // their own.  The workgroups of column tile 0 also write the normalised rows (bf16, the weight-gradient GEMM's operand) and the
 // row mean / rstd (the LayerNorm backward's inputs) when asked to.
 template <int KTT, int WMI, bool LNA>
@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     // global -> register prefetch, TWO stages deep: 4 chunks of A and 4 of W per thread per stage (16 bytes each), two register
     // sets.  Iteration kt issues the loads of stage kt+2, multiplies stage kt, and only then parks stage kt+1 (issued one
     // iteration ago) in the LDS buffer that stage kt-1 vacated: a load has a whole iteration plus a multiply to arrive.
-    gbf16x8 pa[2][LNA ? 1 : ACH], pw[2][4];
-    float4 paf[2][LNA ? ACH : 1][2], pg[2][2], pb[2][2];      // LNA: fp32 chunks of U, and the gamma / beta chunk of the stage
+    gbf16x8 pa[2][ACH], pw[2][4];
+    float4 pg[2][2], pb[2][2];                                // LNA: the gamma / beta chunk of the stage
     float mu[ACH], rsd[ACH];
     const int crow = tid >> 3, ckc = (tid & 7) * 8;           // chunk c = tid + 256*i -> row = crow + 32*i, k offset ckc
     size_t aoff[ACH], woff[4];
@@ -96,12 +96,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     }
 #define GM3D_LOAD_STAGE(SET, K0)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-        if (LNA) {                                                                        \
-            if (i < ACH) {                                                                \
-                paf[SET][LNA ? i : 0][0] = *reinterpret_cast<const float4*>(Af + aoff[i] + (K0));      \
-                paf[SET][LNA ? i : 0][1] = *reinterpret_cast<const float4*>(Af + aoff[i] + (K0) + 4);  \
-            }                                                                             \
-        } else if (i < ACH) pa[SET][LNA ? 0 : i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0)); \
+        if (i < ACH) pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));  \
         pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + (K0));               \
     }                                                                                     \
     if (LNA) {                                                                            \
@@ -118,23 +113,23 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
             const int row = crow + 32 * i;                                                \
             if (i < ACH) {                                                                \
                 if (LNA) {                                                                \
-                    const float4 x0 = paf[SET][LNA ? i : 0][0], x1 = paf[SET][LNA ? i : 0][1];            \
+                    const gbf16x8 xv = pa[SET][i];                                        \
                     const float4 g0 = pg[SET][0], g1 = pg[SET][1], b0 = pb[SET][0], b1 = pb[SET][1];      \
                     const float m_ = mu[i], r_ = rsd[i];                                  \
                     gbf16x8 hv;                                                           \
-                    hv[0] = (bf16_t)((x0.x - m_) * r_ * g0.x + b0.x);                     \
-                    hv[1] = (bf16_t)((x0.y - m_) * r_ * g0.y + b0.y);                     \
-                    hv[2] = (bf16_t)((x0.z - m_) * r_ * g0.z + b0.z);                     \
-                    hv[3] = (bf16_t)((x0.w - m_) * r_ * g0.w + b0.w);                     \
-                    hv[4] = (bf16_t)((x1.x - m_) * r_ * g1.x + b1.x);                     \
-                    hv[5] = (bf16_t)((x1.y - m_) * r_ * g1.y + b1.y);                     \
-                    hv[6] = (bf16_t)((x1.z - m_) * r_ * g1.z + b1.z);                     \
-                    hv[7] = (bf16_t)((x1.w - m_) * r_ * g1.w + b1.w);                     \
+                    hv[0] = (bf16_t)(((float)xv[0] - m_) * r_ * g0.x + b0.x);             \
+                    hv[1] = (bf16_t)(((float)xv[1] - m_) * r_ * g0.y + b0.y);             \
+                    hv[2] = (bf16_t)(((float)xv[2] - m_) * r_ * g0.z + b0.z);             \
+                    hv[3] = (bf16_t)(((float)xv[3] - m_) * r_ * g0.w + b0.w);             \
+                    hv[4] = (bf16_t)(((float)xv[4] - m_) * r_ * g1.x + b1.x);             \
+                    hv[5] = (bf16_t)(((float)xv[5] - m_) * r_ * g1.y + b1.y);             \
+                    hv[6] = (bf16_t)(((float)xv[6] - m_) * r_ * g1.z + b1.z);             \
+                    hv[7] = (bf16_t)(((float)xv[7] - m_) * r_ * g1.w + b1.w);             \
                     *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = hv;           \
                     if (Hout && tile_n == 0 && m0 + row < M)                              \
                         *reinterpret_cast<gbf16x8*>(Hout + (size_t)(m0 + row) * K + (K0) + ckc) = hv;     \
                 } else                                                                    \
-                    *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][LNA ? 0 : i];         \
+                    *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i];   \
             }                                                                             \
             *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];           \
         }                                                                                 \
@@ -330,16 +325,13 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
                        int bias_after_pool = 0, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr,
                        const GemmLn* ln = nullptr) {
     using namespace gm3d;
-    if (ln) {
-        if (!ln->U || !ln->stats || !ln->gamma || !ln->beta || K != 384 || lda % 4 || (ln->mean && !ln->rstd)) return GM3D_EINVAL;
-        A = ln->U;      // only checked for null / alignment below; the kernel reads ln->U
-    }
+    if (ln && (!ln->stats || !ln->gamma || !ln->beta || K != 384 || (ln->mean && !ln->rstd))) return GM3D_EINVAL;
     if (!A || !W || (!C && !G && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp < N)) return GM3D_EINVAL;
     if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
     if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int bm = ln ? 64 : gemm_tile_height(M);     // LayerNorm-on-load: 64-row tiles (the 128-row form would spill its fp32 staging registers)
+    const int bm = ln ? 64 : gemm_tile_height(M);     // LayerNorm-on-load: 64-row tiles (the 128-row form runs out of registers)
     const int tiles_m = (M + bm - 1) / bm, tiles_n = N / GBN;
     if ((long long)tiles_m * tiles_n > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
     const size_t lds_ab = (size_t)2 * (bm + GBN) * GPITCH * sizeof(bf16_t), lds_c = (size_t)bm * GCP * sizeof(float);
@@ -357,7 +349,7 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
         hipLaunchKernelGGL((gemm_tn_bf16_kernel<KTT, WMI, LNA>), dim3(grid), dim3(256), lds, (hipStream_t)stream,             \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total,      \
                            (bf16_t*)G, ldg, (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart,        \
-                           ln ? ln->U : nullptr, ln ? ln->stats : nullptr, ln ? ln->gamma : nullptr, ln ? ln->beta : nullptr,  \
+                           nullptr, ln ? ln->stats : nullptr, ln ? ln->gamma : nullptr, ln ? ln->beta : nullptr,  \
                            ln ? ln->eps : 0.f, ln ? (bf16_t*)ln->H : nullptr, ln ? ln->mean : nullptr, ln ? ln->rstd : nullptr); \
     }
 #define GM3D_GEMM_LAUNCH(KTT, WMI) GM3D_GEMM_LAUNCH_(KTT, WMI, false)
@@ -407,13 +399,13 @@ extern "C" int gm3d_gemm_tn_bf16_gelu_bwd(const void* dO, const void* Wt, const 
     return gemm_launch(dO, Wt, bias, dF, M, N, K, lda, ldw, lddf, nullptr, 0, stream, nullptr, nullptr, 0, 0, F, ldf, colpart);
 }
 
-extern "C" int gm3d_gemm_tn_bf16_lna(const float* U, const float* stats, const float* gamma, const float* beta, float eps, const void* W,
+extern "C" int gm3d_gemm_tn_bf16_lna(const void* U16, const float* stats, const float* gamma, const float* beta, float eps, const void* W,
                                      const float* bias, void* C, void* G, void* H, float* mean, float* rstd, int M, int N, int K, int ldu,
                                      int ldw, int ldc, int ldg, gm3d_stream_t stream) {
     GemmLn ln;
-    ln.U = U; ln.stats = stats; ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.H = H; ln.mean = mean; ln.rstd = rstd;
+    ln.stats = stats; ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.H = H; ln.mean = mean; ln.rstd = rstd;
     if (G && !bias) return GM3D_EINVAL;
-    return gemm_launch(U, W, bias, C, M, N, K, ldu, ldw, ldc, G, ldg, stream, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, &ln);
+    return gemm_launch(U16, W, bias, C, M, N, K, ldu, ldw, ldc, G, ldg, stream, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, &ln);
 }
 
 extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gemm_tile_height(M) - 1) / gemm_tile_height(M); }

@@ -34,7 +34,7 @@ __device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned dst) {
 // WMI: 32-row MFMA tiles per wave in M (1: 64-row workgroup tile, 2: 128-row)
 // RES: residual epilogue of a transformer block's proj / fc2 (N = 384 = the LayerNorm width): instead of C the kernel writes the
 //   fp32 residual stream  U = res + rowscale[row / rows_per_sample] * (A.W^T + bias) (+ add)   -- what gm3d_residual_ln_fwd
-//   computes before it normalises -- and, per row and 128-column tile, the (mean, sum of squared deviations) of those 128
+//   computes before it normalises --, a bf16 copy U16 of it (the consumer's A operand) and, per row and 128-column tile, the (mean, sum of squared deviations) of those 128
 //   values: stats[tile_n][row][2].  The LayerNorm itself is applied by the consumer GEMM while it stages its A operand
 //   (gm3d_gemm_tn_bf16_lna), so the normalised rows never make an HBM round trip of their own.
 template <int WMI, bool RES>
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
                                                            int lda, int ldw, int ldc, int tiles_n, int total_tiles,
                                                            const float* __restrict__ res, const float* __restrict__ rowscale,
                                                            int rows_per_sample, const bf16_t* __restrict__ add, float* __restrict__ U,
-                                                           float* __restrict__ stats) {
+                                                           float* __restrict__ stats, bf16_t* __restrict__ U16) {
     extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
     constexpr int BM = 64 * WMI;
     constexpr int STAGE = (BM + RBN) * 128;                 // bytes
@@ -160,7 +160,10 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += av[e];
             }
-            if (valid) V8<float>::store(U + (size_t)gr * N + n0 + nc, v);
+            if (valid) {
+                V8<float>::store(U + (size_t)gr * N + n0 + nc, v);
+                V8<bf16_t>::store(U16 + (size_t)gr * N + n0 + nc, v);          // what the consumer GEMM stages (half the bytes)
+            }
             float sm = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) sm += v[e];
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
 
 static int ring_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc, int bm,
                        gm3d_stream_t stream, const float* res, const float* rowscale, int rows_per_sample, const void* add, float* U,
-                       float* stats) {
+                       float* stats, void* U16) {
     using namespace gm3d;
     if (!A || !W || (!C && !U) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (N % RBN || K % RBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
@@ -220,7 +223,7 @@ static int ring_launch(const void* A, const void* W, const float* bias, void* C,
         }                                                                                                                \
         hipLaunchKernelGGL((gemm_tn_ring_kernel<WMI, RES>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
                            (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, res, rowscale,    \
-                           rows_per_sample, (const bf16_t*)add, U, stats);                                               \
+                           rows_per_sample, (const bf16_t*)add, U, stats, (bf16_t*)U16);                                 \
     }
     if (U) {
         if (bm == 64) GM3D_RING_LAUNCH(1, true) else GM3D_RING_LAUNCH(2, true)
@@ -235,12 +238,12 @@ static int ring_launch(const void* A, const void* W, const float* bias, void* C,
 extern "C" int gm3d_gemm_tn_bf16_ring(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
                                       int ldc, int bm, gm3d_stream_t stream) {
     if (!C) return GM3D_EINVAL;
-    return ring_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, bm, stream, nullptr, nullptr, 1, nullptr, nullptr, nullptr);
+    return ring_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, bm, stream, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr);
 }
 
 extern "C" int gm3d_gemm_tn_bf16_res(const void* A, const void* W, const float* bias, const float* res, const float* rowscale,
-                                     int rows_per_sample, const void* add, float* U, float* stats, int M, int N, int K, int lda,
-                                     int ldw, int bm, gm3d_stream_t stream) {
-    if (!res || !U || !stats || N != 384 || (rowscale && rows_per_sample < 1)) return GM3D_EINVAL;
-    return ring_launch(A, W, bias, nullptr, M, N, K, lda, ldw, 0, bm, stream, res, rowscale, rows_per_sample, add, U, stats);
+                                     int rows_per_sample, const void* add, float* U, void* U16, float* stats, int M, int N, int K,
+                                     int lda, int ldw, int bm, gm3d_stream_t stream) {
+    if (!res || !U || !U16 || !stats || N != 384 || (rowscale && rows_per_sample < 1)) return GM3D_EINVAL;
+    return ring_launch(A, W, bias, nullptr, M, N, K, lda, ldw, 0, bm, stream, res, rowscale, rows_per_sample, add, U, stats, U16);
 }

@@ -354,22 +354,22 @@ class TransformerStackFn(torch.autograd.Function):
                     yield
                     qkv = _mm(h1, weight_cache.get(wqkv, adt))
                 else:       # u, st1: the previous block's fc2 epilogue
-                    qkv, m1, r1 = gemm.linear_lna(u, st1, ln1w, ln1b, eps, weight_cache.get(wqkv, adt), None,
+                    qkv, m1, r1 = gemm.linear_lna(u16, st1, ln1w, ln1b, eps, weight_cache.get(wqkv, adt), None,
                                                   h_out=H1[i] if need else None, want_stats=need)
                 yield
                 a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
                 yield
-                x1, st2 = gemm.linear_res(a, weight_cache.get(wproj, adt), bproj, u, dp1, T, None)
+                x1, x16, st2 = gemm.linear_res(a, weight_cache.get(wproj, adt), bproj, u, dp1, T, None)
                 yield
                 W1 = weight_cache.get(w1, adt)
-                f, g, m2, r2 = gemm.linear_lna(x1, st2, ln2w, ln2b, eps, W1, b1, gelu=True,
+                f, g, m2, r2 = gemm.linear_lna(x16, st2, ln2w, ln2b, eps, W1, b1, gelu=True,
                                                f_out=torch.empty(R, W1.shape[0], dtype=adt, device=dev) if need else None,
                                                g_out=GG[i] if need else None, h_out=H2[i] if need else None, want_stats=need)
                 yield
                 if need:
                     saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
                 if i + 1 < nblk:
-                    u, st1 = gemm.linear_res(g, weight_cache.get(w2, adt), b2, x1, dp2, T, posa)
+                    u, u16, st1 = gemm.linear_res(g, weight_cache.get(w2, adt), b2, x1, dp2, T, posa)
                 else:
                     o = _mm(g, weight_cache.get(w2, adt))
                     res, y, bias, rs = x1, o, b2, dp2

@@ -46,24 +46,32 @@ def linear_tn_ring(x, w, bias=None, out=None, bm=None):
     return out
 
 
-FUSE_LN = os.environ.get("GM3D_FUSE_LN", "1") == "1"     # LayerNorm folded into the producer / consumer GEMMs (fused.py)
+# LayerNorm folded into the producer / consumer GEMMs (fused.py).  OFF: measured on MI355X at B = 128 (same-box A/B, round 2) the
+# step is 2.5 % SLOWER with it (8.50 vs 8.29 ms) although 97 of 111 LayerNorm launches disappear -- the pass is dominated by the
+# fp32 residual stream (read 4 + write 4 of its 14 bytes per element), which the fusion cannot remove, only move into GEMM
+# epilogues where it is serialised behind the MFMA loop (+5.7 us per producer, +6 us per consumer vs 6.5-10 us per LayerNorm
+# launch).  Kept as tested kernels (tests/test_gpu_fused_ln.py); not an environment switch.
+FUSE_LN = False
 
 
 def linear_res(x, w, bias, res, rowscale, rows_per_sample, add, bm=None):
-    """proj / fc2 with the residual epilogue: -> (U (M,384) f32 = res + rowscale * (bf16(x @ w^T) + bias) + add, stats (3,M,2) f32)."""
+    """proj / fc2 with the residual epilogue: -> (U (M,384) f32 = res + rowscale * (bf16(x @ w^T) + bias) + add, its bf16 copy,
+    stats (3,M,2) f32 = per 128-column tile (mean, sum of squared deviations))."""
     M, K = x.shape
     N = w.shape[0]
     U = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    U16 = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     stats = torch.empty(3, M, 2, dtype=torch.float32, device=x.device)
     if bm is None:
         bm = 64 if M <= 4096 else 128
     _launch("gm3d_gemm_tn_bf16_res", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_res, _ptr(x), _ptr(w), _ptr(bias), _ptr(res),
-            _ptr(rowscale), int(rows_per_sample), _ptr(add), _ptr(U), _ptr(stats), M, N, K, x.stride(0), w.stride(0), int(bm), _stream())
-    return U, stats
+            _ptr(rowscale), int(rows_per_sample), _ptr(add), _ptr(U), _ptr(U16), _ptr(stats), M, N, K, x.stride(0), w.stride(0), int(bm),
+            _stream())
+    return U, U16, stats
 
 
 def linear_lna(U, stats, gamma, beta, eps, w, bias=None, gelu=False, f_out=None, g_out=None, h_out=None, want_stats=False):
-    """LayerNorm(U) @ w^T (+ bias) with the normalisation applied while the A operand is staged.
+    """LayerNorm(U) @ w^T (+ bias) with the normalisation applied while the A operand is staged; U = the bf16 copy of the stream.
     gelu=False -> (C (M,N) bf16, mean, rstd); gelu=True -> (f_out | None, G = GELU(.. + bias), mean, rstd).  h_out (M,384) bf16
     receives the normalised rows, mean / rstd (M) f32 are produced when want_stats."""
     M, K = U.shape

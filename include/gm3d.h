@@ -325,15 +325,19 @@ int gm3d_gemm_tn_bf16_gelu_bwd(const void *dO, const void *Wt, const void *F, co
 /* LayerNorm folded into the GEMMs around it (timm Block norm1 / norm2 + the residual adds, Point-MAE_SA3D/models/Point_MAE.py:128-146):
  *   gm3d_gemm_tn_bf16_res   proj / fc2 (N = 384) whose epilogue writes the fp32 residual stream
  *                           U = res + rowscale[row / rows_per_sample] * (bf16(A.W^T) + bias) + add   (rowscale, add may be NULL)
- *                           and stats (3, M, 2) f32 = per row and 128-column tile (mean, sum of squared deviations);
- *   gm3d_gemm_tn_bf16_lna   qkv / fc1 (K = 384) that reads U and stats, normalises (gamma, beta, eps) while staging its A operand and
+ *                           its bf16 copy U16, and stats (3, M, 2) f32 = per row and 128-column tile (mean, sum of squared
+ *                           deviations) of the fp32 values;
+ *   gm3d_gemm_tn_bf16_lna   qkv / fc1 (K = 384) that reads U16 and stats, normalises (gamma, beta, eps) while staging its A operand and
  *                           computes C = LN(U).W^T + bias (G == NULL) or F (optional) / G = GELU(..) like gm3d_gemm_tn_bf16_gelu;
  *                           H (M,384) bf16, mean / rstd (M) f32 (all optional): the normalised rows and the row statistics, for the
  *                           backward pass.
- * Together they replace GEMM -> gm3d_residual_ln_fwd -> GEMM: same arithmetic up to the order the row statistics are summed in. */
+ * Together they replace GEMM -> gm3d_residual_ln_fwd -> GEMM in the bf16 (throughput) mode: the statistics are those of the fp32
+ * stream; the value that is normalised is the stream rounded to bf16 (an error of at most one bf16 half-ulp of |u| / sigma per
+ * element, i.e. of the size of the rounding of the normalised row itself).  The fp32 parity mode keeps the three-kernel form. */
 int gm3d_gemm_tn_bf16_res(const void *A, const void *W, const float *bias, const float *res, const float *rowscale, int rows_per_sample,
-                          const void *add, float *U, float *stats, int M, int N, int K, int lda, int ldw, int bm, gm3d_stream_t stream);
-int gm3d_gemm_tn_bf16_lna(const float *U, const float *stats, const float *gamma, const float *beta, float eps, const void *W,
+                          const void *add, float *U, void *U16, float *stats, int M, int N, int K, int lda, int ldw, int bm,
+                          gm3d_stream_t stream);
+int gm3d_gemm_tn_bf16_lna(const void *U16, const float *stats, const float *gamma, const float *beta, float eps, const void *W,
                           const float *bias, void *C, void *G, void *H, float *mean, float *rstd, int M, int N, int K, int ldu, int ldw,
                           int ldc, int ldg, gm3d_stream_t stream);
 int gm3d_gemm_tile_rows(int M);

@@ -1,6 +1,7 @@
-"""-m gpu: LayerNorm folded into the GEMMs around it (gm3d_gemm_tn_bf16_res / gm3d_gemm_tn_bf16_lna, fused.TransformerStackFn) against
-the three-kernel form it replaces (GEMM -> gm3d_residual_ln_fwd -> GEMM): the residual stream must be IDENTICAL (same products, same
-rounding points), the normalised rows and everything downstream equal up to the order the row statistics are summed in."""
+"""-m gpu: LayerNorm folded into the GEMMs around it (gm3d_gemm_tn_bf16_res / gm3d_gemm_tn_bf16_lna, fused.TransformerStackFn with
+gemm.FUSE_LN) against the three-kernel form it replaces (GEMM -> gm3d_residual_ln_fwd -> GEMM): the residual stream must be
+IDENTICAL (same products, same rounding points), the row statistics exact, the normalised rows within the stated bf16 bound.
+The folded form is OFF in the product (measured 2.5 % slower on the step); these tests keep its kernels honest."""
 import pytest
 import torch
 
@@ -24,8 +25,9 @@ def test_residual_epilogue_and_layernorm_on_load(M, K, with_add, with_scale):
     # reference: ring GEMM (bit-identical product) -> stand-alone residual LayerNorm
     y = gemm.linear_tn_ring(a, w)
     u_ref, h_ref, m_ref, r_ref = fused.residual_ln_fwd(res, y, bias, rs, T, add, gamma, beta, 1e-5, torch.bfloat16, M)
-    U, stats = gemm.linear_res(a, w, bias, res, rs, T, add)
+    U, U16, stats = gemm.linear_res(a, w, bias, res, rs, T, add)
     assert float((U - u_ref).abs().max()) <= 1e-6 * float(u_ref.abs().max())       # same sums, FMA contraction aside
+    assert torch.equal(U16, U.bfloat16())
     # the per-tile statistics against torch
     Ut = U.view(M, 3, 128)
     assert torch.allclose(stats[:, :, 0].t(), Ut.mean(-1), rtol=1e-5, atol=1e-6)
@@ -35,15 +37,15 @@ def test_residual_epilogue_and_layernorm_on_load(M, K, with_add, with_scale):
     w1 = (torch.randn(1536, C, device="cuda", generator=g) / C ** 0.5).bfloat16()
     b1 = torch.randn(1536, device="cuda", generator=g) * 0.1
     h = torch.empty(M, C, device="cuda", dtype=torch.bfloat16)
-    c, mean, rstd = gemm.linear_lna(U, stats, gamma, beta, 1e-5, wq, None, h_out=h, want_stats=True)
-    assert float((mean - m_ref).abs().max()) <= 1e-5 and float((rstd / r_ref - 1).abs().max()) <= 1e-5
-    # the normalised rows: one bf16 ulp at most where the statistics differ in the last bit
-    assert float((h.float() - h_ref.float()).abs().max()) <= 2.0 ** -7 * float(h_ref.float().abs().max())
-    assert float((h.float() - h_ref.float()).abs().mean()) <= 1e-4
+    c, mean, rstd = gemm.linear_lna(U16, stats, gamma, beta, 1e-5, wq, None, h_out=h, want_stats=True)
+    assert float((mean - m_ref).abs().max()) <= 1e-5 and float((rstd / r_ref - 1).abs().max()) <= 1e-5       # exact statistics
+    # the normalised rows: the stream enters rounded to bf16 -> |error| <= 2^-9 |u| * rstd * gamma (+ the final rounding)
+    bound = (2.0 ** -8 * U.abs() * rstd.unsqueeze(1) * gamma + 2.0 ** -7 * h_ref.float().abs() + 1e-3)
+    assert bool(((h.float() - h_ref.float()).abs() <= bound).all())
     want = gemm.linear_tn(h, wq)                      # the same kernel on the rows the fused launch wrote
     assert torch.equal(c, want)
     f = torch.empty(M, 1536, device="cuda", dtype=torch.bfloat16)
-    f2, g2, _, _ = gemm.linear_lna(U, stats, gamma, beta, 1e-5, w1, b1, gelu=True, f_out=f)
+    f2, g2, _, _ = gemm.linear_lna(U16, stats, gamma, beta, 1e-5, w1, b1, gelu=True, f_out=f)
     fw, gw = gemm.linear_gelu(h, w1, b1, f_out=torch.empty_like(f))
     assert torch.equal(f2, fw) and torch.equal(g2, gw)
 
