@@ -29,6 +29,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+PMC_FILE = "r02_pmc_fetch_write_per_launch.json"     # tools/pmc_summary.py over the two --pmc passes of this bench (profiles/README.md)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense
 
 # SURVEY.md 8(d) per-unit algorithmic figures (bytes unless noted) -> per launch
@@ -84,14 +85,18 @@ def _gemm_grid(meta):
 
 def pmc_traffic(kernel, dtype, metas=()):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc
-    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r01_n_pmc_fetch_write_per_launch.json), corrected as
+    WRITE_SIZE runs of this same bench, eager, summarised in profiles/r02_pmc_fetch_write_per_launch.json), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: counters are in KB, and FETCH_SIZE reports half of a coalesced stream.
     Launch-weighted mean over the kernel's shapes in the step.  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", "r01_n_pmc_fetch_write_per_launch.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     if not os.path.exists(path):
         return None
-    if kernel.startswith("gm3d_gemm_tn_bf16"):
-        # the four GEMM entry points share one kernel: pick the PMC rows by launch grid (= the timed launches' tile counts)
+    if kernel == "gm3d_gemm_tn_bf16_ring":
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_ring_kernel")]
+    elif kernel == "gm3d_gemm_nt_bf16":
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_nt_bf16_kernel")]
+    elif kernel.startswith("gm3d_gemm_tn_bf16"):
+        # the GEMM entry points share one kernel: pick the PMC rows by launch grid (= the timed launches' tile counts)
         grids = {_gemm_grid(m) for m in metas}
         rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_bf16_kernel") and r["grid_threads"] in grids]
     else:
@@ -159,7 +164,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
     if args.gpus != world and rank == 0 and world > 1:
@@ -176,7 +192,7 @@ def main():
     model_ema = E.ModelEma(model, decay=E.ema_decay_for_epoch(args.epoch))
     use_graph = not args.no_graph
     # data-parallel: lay the flat gradient buffer out by backward segment so that each segment is one all-reduce range
-    segmented = use_dist and os.environ.get("GM3D_DDP_SEGMENTED", "1") == "1" and not args.no_graph
+    segmented = use_dist and not args.no_graph
     optimizer = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=model_ema,
                                   segment_of=E.ddp_segment if segmented else None)
     grad_sync = E.GradSync.from_flat(optimizer, bucket_bytes=args.bucket_mb << 20) if use_dist else None
@@ -253,15 +269,19 @@ def main():
 
     fence()
     ops.set_kernel_timer(timer)
-    t0 = time.perf_counter()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step spread: events between the steps,
+    t0 = time.perf_counter()                                                          # no synchronisation inside the timed region
     for i in range(args.steps):
+        marks[i].record()
         out = step(args.warmup + i)
         if os.environ.get("GM3D_BENCH_DEBUG"):
             print("step", i, {k: float(v) for k, v in out.items() if v.numel() == 1}, "lr", [float(g["lr"]) for g in optimizer.param_groups],
                   "in", float(graphed.static_in.abs().mean()) if use_graph else None, file=sys.stderr)
+    marks[args.steps].record()
     fence()
     dt = time.perf_counter() - t0
     ops.set_kernel_timer(None)
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -319,6 +339,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step_spread": {"min": round(step_ms[0], 4), "median": round(step_ms[len(step_ms) // 2], 4),
+                                   "max": round(step_ms[-1], 4), "how": "HIP events between consecutive steps of the timed region (rank 0)"},
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,

@@ -307,11 +307,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 
 }  // namespace gm3d
 
-// 64-row tiles for the short token streams (3200 rows x N/128 column tiles is 75-300 workgroups for 512 slots), 128 otherwise;
-// GM3D_GEMM_BM=64|128 forces one (measurements)
+// 64-row tiles for the short token streams (3200 rows x N/128 column tiles is 75-300 workgroups for 512 slots), 128 otherwise
 static int gemm_tile_height(int M) {
-    static const int forced = getenv("GM3D_GEMM_BM") ? atoi(getenv("GM3D_GEMM_BM")) : 0;
-    if (forced == 64 || forced == 128) return forced;
     return M <= 4096 ? 64 : 128;
 }
 

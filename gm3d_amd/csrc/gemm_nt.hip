@@ -8,12 +8,12 @@
 //
 // Design (MI355X).  Neither operand has the reduction index contiguous, which is what an MFMA fragment wants (8 consecutive k
 // per lane).  Both are therefore staged as they lie in memory -- [32 rows][128 columns] bf16 tiles with coalesced 16-byte
-// pieces, by LDS-DMA (global_load_lds_dwordx4: no staging registers, four tiles deep, two stages in flight behind a COUNTED
+// pieces, by LDS-DMA (global_load_lds_dwordx4: no staging registers, a ring of three stages, two in flight behind a COUNTED
 // s_waitcnt vmcnt) -- and every fragment is read with the hardware-transposing ds_read_b64_tr_b16 (4 rows x 16 columns per
 // 16-lane group, column-major out).  The LDS image is the 256-byte-row image with the chunk XOR
 // ((row & 3) << 2 | (row >> 2) & 3) (conflict-free transposed reads); LDS-DMA writes lane-linear, so the XOR sits on the
 // per-lane SOURCE address.  128 x 128 output tile per 256-thread workgroup (4 waves x (64 x 64) = 2 x 2 MFMA 32x32x16 tiles),
-// 64 KiB of LDS -> two workgroups per CU.  Long reductions over few output tiles (the 4-block decoders: 27 tiles per
+// 48 KiB of LDS -> three workgroups per CU, or two beside a workgroup of the backward chain the launch runs next to.  Long reductions over few output tiles (the 4-block decoders: 27 tiles per
 // weight kind and block) are split over row ranges into fp32 partial slabs that gm3d_sum_few_rows adds in a fixed order
 // (deterministic; no atomics).
 #include "common.hpp"
@@ -28,7 +28,7 @@ typedef __attribute__((address_space(3))) nbf16x4 lds_nbf16x4;
 constexpr int NT_BR = 32;                 // reduction rows per stage
 constexpr int NT_TILE = NT_BR * 256;      // bytes of one [32][128] bf16 tile
 constexpr int NT_STAGE = 2 * NT_TILE;     // dY tile + X tile
-constexpr int NT_NBUF = 4;
+constexpr int NT_NBUF = 3;
 
 __device__ __forceinline__ int nt_f(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
 
@@ -113,17 +113,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
     GM3D_NT_STAGE(0)
     if (nst > 1) GM3D_NT_STAGE(1)
     for (int st = 0; st < nst; ++st) {
-        // every wave issues 4 pieces per stage: stage st has landed (this wave's share) when at most the pieces of the stages
+        // every wave issues 4 pieces per stage: stage st has landed (this wave's share) when at most the pieces of the one stage
         // issued after it are outstanding
-        if (st + 2 < nst) {
-            GM3D_NT_STAGE(st + 2)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else if (st + 1 < nst) {
+        if (st + 1 < nst) {
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();                   // ... and everybody else's share
+        __builtin_amdgcn_s_barrier();                   // ... and everybody else's share; everybody is past its reads of stage st-1,
+        if (st + 2 < nst) GM3D_NT_STAGE(st + 2)         // whose buffer (three in the ring) stage st+2 now refills
         const unsigned char* ys = nsm + (st % NT_NBUF) * NT_STAGE;
         const unsigned char* xs = ys + NT_TILE;
 #pragma unroll
@@ -138,9 +136,6 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        // buffer (st + 3) % 4 is restaged by the NEXT iteration's issue; every wave is past its reads of it (stage st - 1)
-        // once it has passed this iteration's barrier, and a wave reaches the next issue only after its own reads of stage st
-        // have returned (the MFMAs above consumed them)
     }
 #undef GM3D_NT_STAGE
     // result: rows (registers) = n, columns (lanes) = k: 128 contiguous bytes per half-wave and register

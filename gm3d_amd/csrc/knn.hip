@@ -25,9 +25,6 @@ constexpr int KNN_BLOCK = 256;
 // workgroup amortise that, but a query is a long chain of dependent wave-wide steps and only many resident waves hide it:
 // 4 per workgroup (one per wave) until the grid exceeds ~8 waves per SIMD, then 8 / 16.
 static int knn_qpb(int B, int G) {
-    static int forced = -1;
-    if (forced < 0) { const char* e = getenv("GM3D_KNN_QPB"); forced = e ? atoi(e) : 0; }
-    if (forced == 4 || forced == 8 || forced == 16) return forced;
     const long long queries = (long long)B * G;
     return queries <= 8192 * 2 ? 4 : (queries <= 8192 * 8 ? 8 : 16);
 }
@@ -238,8 +235,7 @@ static int launch_knn(const float* ref, const float* query, int B, int N, int G,
     }
     const int qpb = knn_qpb(B, G);
     dim3 grid((G + qpb - 1) / qpb, B);
-    static int use_select = -1;
-    if (use_select < 0) { const char* e = getenv("GM3D_KNN_SELECT"); use_select = e ? atoi(e) : 1; }
+    const int use_select = 1;
     // registers hold the cloud's distances: selection by bisection (see knn_select_kernel).  Measured on MI355X: 2.0-2.5x the
     // insertion kernel at N = 1024, k = 32 (81 -> 32 us for 128 x 64 queries); at N = 2048, k = 16 (twice the registers to scan per
     // bisection step, half the insertions) the insertion kernel is 16 % faster, so longer clouds stay there unless forced (2).

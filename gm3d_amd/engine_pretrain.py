@@ -589,7 +589,7 @@ class GraphedPretrainStep:
         self.graph = torch.cuda.CUDAGraph()
         # with a process group alive its watchdog thread polls events; only the capturing thread's calls may abort a capture
         import os
-        mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
+        mode = "thread_local" if dist.is_initialized() else "global"
         if not two:
             self.graph2 = None
             with torch.cuda.graph(self.graph, capture_error_mode=mode):
@@ -683,7 +683,7 @@ class SegmentedDDPStep:
                 torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             import os
-            mode = os.environ.get("GM3D_CAPTURE_MODE") or ("thread_local" if dist.is_initialized() else "global")
+            mode = "thread_local" if dist.is_initialized() else "global"
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
             with torch.cuda.graph(self.graphs[0], capture_error_mode=mode):
                 self.out = self._phase1(self.static_in)

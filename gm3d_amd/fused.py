@@ -216,8 +216,8 @@ def _wgrad_batched(dy, x, out=None):
     return _wgrad_batched_plain(dy, x, out)
 
 
-SUM_FEW_ROWS = __import__("os").environ.get("GM3D_SUM_FEW_ROWS", "1") == "1"
-WGRAD_ROW_SPLIT = int(__import__("os").environ.get("GM3D_WGRAD_SPLIT", "4"))   # 0 = auto, 1 = off, n = fixed n-way for <=4-block stacks
+SUM_FEW_ROWS = True
+WGRAD_ROW_SPLIT = 4      # library fallback only (shapes the NT kernel does not take): 0 = auto, 1 = off, n = n-way for <=4-block stacks
 
 
 _BMM_OUT_OK = [True]     # torch.bmm(..., out_dtype=, out=) available?
@@ -250,7 +250,7 @@ def _run_deferred(reg):
         job()
 
 _wgrad_streams = {}
-ASYNC_WGRAD = __import__("os").environ.get("GM3D_ASYNC_WGRAD", "1") == "1"
+ASYNC_WGRAD = True       # (tests flip it)
 
 
 class async_wgrad:
@@ -595,8 +595,8 @@ class _NoCtx:
         pass
 
 
-LOCKSTEP = __import__("os").environ.get("GM3D_LOCKSTEP", "1") == "1"     # interleave the launches of the parallel inference chains
-NOGRAD_SPLIT = int(__import__("os").environ.get("GM3D_NOGRAD_SPLIT", "2"))    # parallel chains of an inference-only stack (1 = off)
+LOCKSTEP = True          # interleave the launches of the parallel inference chains (measured: same speed as chain after chain)
+NOGRAD_SPLIT = 2         # parallel chains of an inference-only stack (1 = off; measured 2 > 1 > 3 > 4; tests flip it)
 _split_streams = {}
 
 

@@ -8,10 +8,10 @@ from .ops import _launch, _ptr, _stream
 
 import os
 
-ENABLED = os.environ.get("GM3D_OWN_GEMM", "1") == "1"
-FUSE_GELU = os.environ.get("GM3D_FUSE_GELU", "1") == "1"      # fc1 + bias + GELU as one launch in the fused transformer stack
-FUSE_POOL = os.environ.get("GM3D_FUSE_POOL", "1") == "1"      # mini-PointNet conv + max-pool as one launch
-FUSE_GELU_BWD = os.environ.get("GM3D_FUSE_GELU_BWD", "1") == "1"   # fc2 input gradient + GELU backward + fc1 bias-gradient partials
+ENABLED = True            # module attributes below: flipped by the equality tests and tools/, not environment switches
+FUSE_GELU = True          # fc1 + bias + GELU as one launch in the fused transformer stack
+FUSE_POOL = True          # mini-PointNet conv + max-pool as one launch
+FUSE_GELU_BWD = True      # fc2 input gradient + GELU backward + fc1 bias-gradient partials
 
 
 def supported(x, w):
@@ -149,7 +149,7 @@ def linear_pool(x, w, bias, bias_after_pool, want_rows):
     return rows, pooled, arg
 
 
-OWN_WGRAD = os.environ.get("GM3D_OWN_WGRAD", "1") == "1"     # weight-gradient (NT) GEMMs on the hand-written kernel (csrc/gemm_nt.hip)
+OWN_WGRAD = True          # weight-gradient (NT) GEMMs on the hand-written kernel (csrc/gemm_nt.hip)
 
 
 def wgrad_supported(dy, x):

@@ -98,8 +98,8 @@ def drop_path_scales(B, probs, training, device):
 
 # the student's two decoders are independent given x_full: the loss-prediction decoder runs on a second HIP stream (forward, and
 # backward by autograd on the same stream; a captured graph keeps the fork / join as parallel branches).  +3.5 % on the step.
-PARALLEL_DECODERS = os.environ.get("GM3D_PARALLEL_DECODERS", "1") == "1"
-VISIBLE_EMBED = os.environ.get("GM3D_VISIBLE_EMBED", "1") == "1"   # student: last embed conv on the visible groups only
+PARALLEL_DECODERS = True      # module attribute (the equality tests flip it), not an environment switch
+VISIBLE_EMBED = True          # student: last embed conv on the visible groups only (tests flip it)
 _decoder_streams = {}
 
 

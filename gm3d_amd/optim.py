@@ -76,7 +76,7 @@ class _GradSlots:
 
 
 grad_slots = _GradSlots()
-ENABLE_DIRECT_WGRAD = os.environ.get("GM3D_DIRECT_WGRAD", "1") == "1"
+ENABLE_DIRECT_WGRAD = True    # weight gradients written straight into the flat buffer (tests flip it)
 
 
 class FlatAdamWEma(torch.optim.Optimizer):

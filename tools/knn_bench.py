@@ -1,4 +1,4 @@
-"""KNN grouping kernel timing (captured train of launches, HIP events): python tools/knn_bench.py   [GM3D_KNN_QPB=4|8|16]"""
+"""KNN grouping kernel timing (captured train of launches, HIP events): python tools/knn_bench.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
