@@ -153,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
 }  // namespace gm3d
 
 extern "C" int gm3d_gemm_nt_splits(int batch, int R, int N, int K) {
-    // the smallest power-of-two row split (<= 64, gm3d_sum_few_rows' limit) that offers the chip >= 512 workgroups while every
+    // the smallest power-of-two row split (<= 64, gm3d_sum_few_rows' limit) that offers the chip >= 400 workgroups (tools/wgrad_split_sweep.py: the optimum sits at 400-600) while every
     // split keeps >= 512 rows (16 stages)
     if (batch < 1 || R < 1 || N < 1 || K < 1) return 1;
     const long long tiles = (long long)batch * (N / 128) * (K / 128);
     int s = 1;
-    while (tiles * s < 512 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 512) s *= 2;
+    while (tiles * s < 400 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 512) s *= 2;
     return s;
 }
 

@@ -35,16 +35,17 @@ def timeit(fn, iters=20):
 shapes = [(12, 3200, 384, 1536), (12, 3200, 1536, 384), (12, 3200, 384, 384), (12, 3200, 1152, 384),
           (4, 8192, 384, 1536), (4, 8192, 1536, 384), (4, 8192, 384, 384), (4, 8192, 1152, 384),
           (1, 262144, 256, 128), (1, 262144, 512, 256), (1, 102400, 384, 512), (1, 8192, 512, 256), (1, 8192, 1024, 384)]
-print("%-28s %10s %10s %8s   splits" % ("(nb, R, N, K)", "own us", "library us", "ratio"))
-for nb, R, N, K in shapes:
-    dy = torch.randn(nb, R, N, device=dev).bfloat16()
-    x = torch.randn(nb, R, K, device=dev).bfloat16()
-    out = torch.empty(nb, N, K, device=dev)
-    own = timeit(lambda: gemm.wgrad_nt(dy, x, out))
-    was = gemm.OWN_WGRAD
-    gemm.OWN_WGRAD = False
-    lib_t = timeit(lambda: fused._wgrad_batched(dy, x, out))
-    gemm.OWN_WGRAD = was
-    fl = 2.0 * nb * R * N * K
-    print("%-28s %10.1f %10.1f %8.2f   %d   (own %.0f TFLOP/s)" % (str((nb, R, N, K)), own, lib_t, lib_t / own,
-          __import__("gm3d_amd._capi", fromlist=["lib"]).lib.gm3d_gemm_nt_splits(nb, R, N, K), fl / own * 1e-6))
+if __name__ == "__main__":
+  print("%-28s %10s %10s %8s   splits" % ("(nb, R, N, K)", "own us", "library us", "ratio"))
+  for nb, R, N, K in shapes:
+      dy = torch.randn(nb, R, N, device=dev).bfloat16()
+      x = torch.randn(nb, R, K, device=dev).bfloat16()
+      out = torch.empty(nb, N, K, device=dev)
+      own = timeit(lambda: gemm.wgrad_nt(dy, x, out))
+      was = gemm.OWN_WGRAD
+      gemm.OWN_WGRAD = False
+      lib_t = timeit(lambda: fused._wgrad_batched(dy, x, out))
+      gemm.OWN_WGRAD = was
+      fl = 2.0 * nb * R * N * K
+      print("%-28s %10.1f %10.1f %8.2f   %d   (own %.0f TFLOP/s)" % (str((nb, R, N, K)), own, lib_t, lib_t / own,
+            __import__("gm3d_amd._capi", fromlist=["lib"]).lib.gm3d_gemm_nt_splits(nb, R, N, K), fl / own * 1e-6))
