@@ -442,6 +442,10 @@ class TransformerStackFn(torch.autograd.Function):
         if fuse_mlp_bwd:
             W2T = gemm.stacked_transpose(w2s)                                                                   # (nblk, C, 4C)^T -> (nblk, 4C, C)
             WPT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 3], adt) for i in range(nblk)])  # (nblk, C, C)
+            # fc1 / qkv input gradients as TN products on the LDS-DMA ring kernel (N = 384 columns, K = 1536 / 1152: its regime;
+            # 9.3-16.8 us against 11.6-21 us for the library's NN form in the step): two more transposed shadows per stack
+            W1T = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 7], adt) for i in range(nblk)])  # (nblk, C, 4C)
+            WQT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 2], adt) for i in range(nblk)])  # (nblk, C, 3C)
         PGL = torch.empty(nblk, gemm.tile_rows(R) if fuse_mlp_bwd else lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32,
                           device=dev)
         SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
@@ -467,14 +471,14 @@ class TransformerStackFn(torch.autograd.Function):
                 dg = d_o @ weight_cache.get(w2, adt)
                 df, _ = bias_gelu_bwd(dg, f, b1, adt, df=DF[i], partial=PGL[i])
             gi[8] = SGL[i]
-            dh2 = df @ weight_cache.get(w1, adt)
+            dh2 = gemm.mm(df, W1T[i]) if fuse_mlp_bwd else df @ weight_cache.get(w1, adt)
             dx1, d_p, _ = residual_ln_bwd(dh2, G, x1, m2, r2, ln2w, dp1, T, None, True, adt, R, dy=DP[i],
                                           partial=PLN[2 * i + 1])
             gi[5], gi[6], gi[4] = SLN[2 * i + 1, 0], SLN[2 * i + 1, 1], SLN[2 * i + 1, 2]
             # attention branch: x1 = u + dp1 * (a @ Wproj^T + bproj)
             da = gemm.mm(d_p, WPT[i]) if fuse_mlp_bwd else d_p @ weight_cache.get(wproj, adt)
             dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
-            dh1 = dqkv @ weight_cache.get(wqkv, adt)
+            dh1 = gemm.mm(dqkv, WQT[i]) if fuse_mlp_bwd else dqkv @ weight_cache.get(wqkv, adt)
             G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
                                         dy=DO[i - 1] if i > 0 else None, partial=PLN[2 * i])
             if dpos is None:

@@ -1,0 +1,13 @@
+"""bench.py with module attributes overridden (A/B of the former environment knobs):
+    python tools/bench_with.py fused.NOGRAD_SPLIT=1 gemm.FUSE_LN=True -- --steps 40 --warmup 10 --no-cpu-baseline"""
+import importlib, os, runpy, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+args = sys.argv[1:]
+cut = args.index("--") if "--" in args else len(args)
+for item in args[:cut]:
+    name, val = item.split("=")
+    mod, attr = name.rsplit(".", 1)
+    setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
+sys.argv = [os.path.join(ROOT, "bench.py")] + args[cut + 1:]
+runpy.run_path(sys.argv[0], run_name="__main__")
