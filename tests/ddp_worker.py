@@ -81,6 +81,21 @@ def run(rank, world, port, out, B=4, steps=3):
         del seg, opt, ema, m
         torch.cuda.empty_cache()
         dist.barrier()
+    # the drop-in epoch loop on two ranks: eager warm-up iterations through GradSync.from_flat (created by train_one_epoch), then the
+    # captured SegmentedDDPStep; each rank feeds its own shard of every batch
+    torch.manual_seed(100 + rank)
+    m = M.mae_vit_base_patch16_dec512d8b().cuda()
+    ema = E.ModelEma(m, 0.999)
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment)
+    eargs = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40,
+                            learning_loss=True)
+    loader = [clouds.gaussian(B * world, 1024, 500 + i)[ids] for i in range(7)]
+    E._warm.clear()
+    stats = E.train_one_epoch(m, loader, opt, torch.device("cuda"), 200, None, args=eargs, model_ema=ema, print_freq=100)
+    torch.cuda.synchronize()
+    torch.save({"params": opt.P.cpu(), "ema": opt.E.cpu(), "stats": {k: float(v) for k, v in stats.items()}},
+               os.path.join(out, "epoch_rank%d.pt" % rank))
+    dist.barrier()
     dist.destroy_process_group()
 
 

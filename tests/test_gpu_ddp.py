@@ -67,3 +67,15 @@ def test_two_rank_graph_equals_eager(ddp_results):
             assert abs(x - y) <= 2e-2 * abs(y), (e0["losses"], g0["losses"])
     worst = float((e0["params"] - g0["params"]).abs().max())
     assert worst <= 2e-2 * float(e0["params"].abs().max()), worst
+
+
+def test_two_rank_train_one_epoch(ddp_results):
+    """The drop-in epoch loop (engine_pretrain.train_one_epoch, P/engine_pretrain.py:38-271) with a process group of two ranks: it builds
+    its own gradient synchroniser (which broadcasts rank 0's state: the ranks were seeded differently), runs the first iterations
+    eagerly and the rest as replays of the captured four-graph step.  Replicas must end bit-identical."""
+    e0, e1 = _load(ddp_results, "epoch")
+    assert torch.equal(e0["params"], e1["params"]) and torch.equal(e0["ema"], e1["ema"])
+    for st in (e0["stats"], e1["stats"]):
+        assert st["replayed_iters"] == 7 - 3 and st["capture_s"] > 0
+        assert all(v == v and abs(v) != float("inf") for v in st.values())
+    assert abs(e0["stats"]["loss"] - e1["stats"]["loss"]) <= 1e-6 * abs(e0["stats"]["loss"])      # the epoch's metric all-reduce
