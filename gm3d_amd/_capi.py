@@ -26,6 +26,7 @@ SIGNATURES = {
     "gm3d_chamfer_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gm3d_chamfer_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "gm3d_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "gm3d_attention_qkv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_residual_ln_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_residual_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -65,6 +66,9 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_lna": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tile_rows": [_i],
     "gm3d_gemm_tn_bf16_ring": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_dma": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_dma_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_dma_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_transpose_bf16_batched": [_vp, _vp, _i, _i, _i, ctypes.c_longlong, _vp],
     "gm3d_token_assemble_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "gm3d_token_assemble_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],

@@ -27,6 +27,7 @@ SOURCES = {
     "gemm.hip": [],
     "gemm_nt.hip": [],
     "gemm_ring.hip": [],
+    "gemm_dma.hip": [],
     "attention_masked.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

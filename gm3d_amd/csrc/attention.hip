@@ -155,40 +155,13 @@ __device__ __forceinline__ void store_tile_t(unsigned char* img, int row0, const
     }
 }
 
-// ===================================================================== forward, bf16
-// NT = number of 32-row tiles = waves (T <= 32 NT).  LDS: Q, K, V images.  Every 16-byte chunk of the head's q|k|v slab is
-// requested up front with coalesced loads (8 lanes per 128-byte row piece), 12 per thread.
+// The attention proper on the three LDS images, by wave w = query tile w of NT.  Oi: image whose rows 32 w .. 32 w + 31 this wave
+// may overwrite to stage its output rows (the Q image itself when nobody else reads those rows afterwards).
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                                float* __restrict__ lse, int T, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int ROWS = 32 * NT, IMG = ROWS * 128;
-    unsigned char* Qi = smem;
-    unsigned char* Ki = Qi + IMG;
-    unsigned char* Vi = Ki + IMG;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
-    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ void attn_core_bf16(const unsigned char* Qi, const unsigned char* Ki, const unsigned char* Vi,
+                                               unsigned char* Oi, int w, int lane, int T, float scale, bf16_t* outp, size_t os,
+                                               float* lsep) {
     const int r = lane & 31, hh = lane >> 5;
-    const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
-    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
-    {
-        uint4 v[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {                      // 3 tiles x ROWS x 8 chunks = 768 NT = 12 x (64 NT threads)
-            const int c = tid + i * 64 * NT;
-            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
-            const int rr = row < T ? row : T - 1;           // clamped, not predicated: the loads all issue back to back
-            v[i] = *reinterpret_cast<const uint4*>(Qg + (size_t)rr * rs + (size_t)tile * os + ch * 8);
-        }
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            const int c = tid + i * 64 * NT;
-            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
-            *reinterpret_cast<uint4*>(smem + tile * IMG + img_off(row, ch)) = row < T ? v[i] : make_uint4(0, 0, 0, 0);
-        }
-    }
-    __syncthreads();
-
     // S^T tiles: rows = keys (regs), cols = queries (lanes)
     f32x16 st[NT];
 #pragma unroll
@@ -233,9 +206,167 @@ __global__ __launch_bounds__(64 * NT) void attn_fwd_bf16_kernel(const bf16_t* __
             o0 = MFMA_BF16(img_tr8(Vi, 32 * t, s, hh, cb, lane), p, o0);
             o1 = MFMA_BF16(img_tr8(Vi, 32 * t, s, hh, 32 + cb, lane), p, o1);
         }
-    // this wave's Q rows are read by nobody else: stage the output tile there and write whole rows
-    store_tile_t(Qi, 32 * w, o0, o1, lane, out + (size_t)b * T * os + (size_t)h * HD, os, T);
-    if (lse && hh == 0 && qrow < T) lse[((size_t)b * H + h) * T + qrow] = m + logf(sum);
+    store_tile_t(Oi, 32 * w, o0, o1, lane, outp, os, T);
+    if (lsep && hh == 0 && qrow < T) lsep[qrow] = m + logf(sum);
+}
+
+// ===================================================================== forward, bf16
+// NT = number of 32-row tiles = waves (T <= 32 NT).  LDS: Q, K, V images.  Every 16-byte chunk of the head's q|k|v slab is
+// requested up front with coalesced loads (8 lanes per 128-byte row piece), 12 per thread.
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void attn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                float* __restrict__ lse, int T, int H, float scale) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int ROWS = 32 * NT, IMG = ROWS * 128;
+    unsigned char* Qi = smem;
+    unsigned char* Ki = Qi + IMG;
+    unsigned char* Vi = Ki + IMG;
+    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+    const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
+    {
+        uint4 v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {                      // 3 tiles x ROWS x 8 chunks = 768 NT = 12 x (64 NT threads)
+            const int c = tid + i * 64 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            const int rr = row < T ? row : T - 1;           // clamped, not predicated: the loads all issue back to back
+            v[i] = *reinterpret_cast<const uint4*>(Qg + (size_t)rr * rs + (size_t)tile * os + ch * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+            const int c = tid + i * 64 * NT;
+            const int tile = c / (ROWS * 8), rc = c - tile * (ROWS * 8), row = rc >> 3, ch = rc & 7;
+            *reinterpret_cast<uint4*>(smem + tile * IMG + img_off(row, ch)) = row < T ? v[i] : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // this wave's Q rows are read by nobody else: the output tile is staged there and written as whole rows
+    attn_core_bf16<NT>(Qi, Ki, Vi, Qi, w, lane, T, scale, out + (size_t)b * T * os + (size_t)h * HD, os,
+                       lse ? lse + ((size_t)b * H + h) * T : nullptr);
+}
+
+// ===================================================================== qkv projection + attention in one launch (bf16, T <= 64)
+// Beneath: timm Attention.forward lines qkv = self.qkv(x) ... x = (attn @ v) (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:113-122)
+// for one (cloud, head): the head's 192 rows of W_qkv (q | k | v slices, 64 x 384 each) times the cloud's 64 x 384 normalised
+// tokens, then the attention of csrc's attn_core_bf16 on the products -- which never leave the CU: they are rounded to bf16 into
+// the three LDS images exactly where attn_fwd_bf16_kernel would have loaded them from HBM.  The projection is the LDS-DMA ring of
+// csrc/gemm_ring.hip on a 64 x 192 tile (stage = 64 token rows + 192 weight rows of 64 k = 32 KiB, 6 stages, LOOK in flight: 1, so that two workgroups share a CU);
+// 4 waves: wave w owns token tile w >> 1 and columns 96 (w & 1) .. +95 of q|k|v.  The attention runs on waves 0 and 1 (query
+// tiles) while, in the training variant, waves 2 and 3 write q|k|v out for the backward.  The workgroup order keeps a cloud's six
+// heads on one XCD (its token tile is fetched from HBM once, then hit in that XCD's L2).
+constexpr int QA_C = 384, QA_KT = QA_C / 64, QA_STAGE = (64 + 192) * 128;
+
+__device__ __forceinline__ void qa_glds16(const void* gsrc, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+template <int LOOK, bool WRITE_QKV>
+__global__ __launch_bounds__(256) void attn_qkv_fwd_bf16_kernel(const bf16_t* __restrict__ hin, const bf16_t* __restrict__ wqkv,
+                                                                bf16_t* __restrict__ out, float* __restrict__ lse,
+                                                                bf16_t* __restrict__ qkv_out, int T, int H, float scale, int total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NBUF = LOOK + 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    const int b = logical / H, h = logical - b * H;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // this lane's share of a stage: 1-KiB pieces p = w + 4 i (i < 8); p < 8: token rows 8p .. 8p+7, else weight rows 8(p-8) ..
+    const int prow = lane >> 3, pslot = lane & 7;
+    const bf16_t* src[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int p = w + 4 * i;
+        if (p < 8) {
+            const int row = 8 * p + prow;
+            const int t = row < T ? row : T - 1;                          // rows past T: clamped here, zeroed in the images
+            const int f = (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+            src[i] = hin + ((size_t)b * T + t) * QA_C + ((pslot ^ f) << 3);
+        } else {
+            const int row = 8 * (p - 8) + prow;                           // 0..191: q rows, k rows, v rows of this head
+            const int f = (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1);
+            src[i] = wqkv + ((size_t)(row >> 6) * H * HD + (size_t)h * HD + (row & 63)) * QA_C + ((pslot ^ f) << 3);
+        }
+    }
+#define GM3D_QA_STAGE(ST)                                                                        \
+    {                                                                                            \
+        const unsigned base = lds0 + ((ST) % NBUF) * QA_STAGE;                                   \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) qa_glds16(src[i] + (ST) * 64, base + 1024 * (w + 4 * i)); \
+    }
+    f32x16 acc[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) acc[j] = zero16();
+    const int wm = (w >> 1) * 32, wn = (w & 1) * 96;
+#pragma unroll
+    for (int s = 0; s < LOOK; ++s) GM3D_QA_STAGE(s)
+    // stage KT_: wait until it has landed (the younger stages in flight may stay out), barrier (everybody is also done with the
+    // buffer stage KT_ + LOOK goes to), refill, multiply
+#define GM3D_QA_ITER(KT_)                                                                                                   \
+    {                                                                                                                       \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * ((QA_KT - 1 - (KT_)) < (LOOK - 1) ? (QA_KT - 1 - (KT_)) : (LOOK - 1))) : "memory"); \
+        __builtin_amdgcn_s_barrier();                                                                                       \
+        if ((KT_) + LOOK < QA_KT) GM3D_QA_STAGE((KT_) + LOOK)                                                               \
+        const unsigned char* as = smem + ((KT_) % NBUF) * QA_STAGE;                                                         \
+        const unsigned char* ws = as + 64 * 128;                                                                            \
+        _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                                     \
+            const bf16x8 fa = img_row(as, wm + r, 2 * s + hh);                                                              \
+            _Pragma("unroll") for (int j = 0; j < 3; ++j) acc[j] = MFMA_BF16(img_row(ws, wn + 32 * j + r, 2 * s + hh), fa, acc[j]); \
+        }                                                                                                                   \
+    }
+    GM3D_QA_ITER(0) GM3D_QA_ITER(1) GM3D_QA_ITER(2) GM3D_QA_ITER(3) GM3D_QA_ITER(4) GM3D_QA_ITER(5)
+#undef GM3D_QA_ITER
+#undef GM3D_QA_STAGE
+    // acc[j][g]: token wm + r, column wn + 32 j + crow(g, hh) of q|k|v.  The images alias ring buffer 0, whose last reader was
+    // stage NBUF * floor(5 / NBUF) < 5 for every LOOK < 5: all waves are past it (the barrier of stage 5).
+    static_assert((QA_KT - 1) % NBUF != 0, "the last stage must not sit in buffer 0");
+    unsigned char* Qi = smem;
+    unsigned char* Ki = smem + 8192;
+    unsigned char* Vi = smem + 16384;
+    unsigned char* Oi = smem + 24576;
+    {
+        const int token = wm + r;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int col = wn + 32 * j;
+            unsigned char* img = smem + (col >> 6) * 8192;
+            const int cbase = (col & 63) >> 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                bf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = token < T ? (bf16_t)acc[j][4 * q + e] : (bf16_t)0.0f;
+                *reinterpret_cast<bf16x4*>(img + img_off(token, cbase + q) + 8 * hh) = pk;
+            }
+        }
+    }
+    __syncthreads();
+    const size_t os = (size_t)H * HD;
+    if (w < 2) {
+        attn_core_bf16<2>(Qi, Ki, Vi, Oi, w, lane, T, scale, out + (size_t)b * T * os + (size_t)h * HD, os,
+                          lse ? lse + ((size_t)b * H + h) * T : nullptr);
+    } else if (WRITE_QKV) {
+        bf16_t* g = qkv_out + (size_t)b * T * 3 * os + (size_t)h * HD;
+        const int t2 = tid - 128;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {                                    // 3 images x 64 rows x 8 chunks = 12 x 128 threads
+            const int c = t2 + 128 * i;
+            const int tile = c >> 9, row = (c >> 3) & 63, ch = c & 7;
+            if (row < T)
+                *reinterpret_cast<uint4*>(g + (size_t)row * 3 * os + (size_t)tile * os + ch * 8) =
+                    *reinterpret_cast<const uint4*>(smem + tile * 8192 + img_off(row, ch));
+        }
+    }
 }
 
 // ===================================================================== forward, f32
@@ -606,6 +737,24 @@ extern "C" int gm3d_attention_fwd(const void* qkv, void* out, float* lse, int B,
     const size_t lds = sizeof(float) * 3 * rows * 64;
     return T <= 64 ? launch_attn(attn_fwd_f32_kernel<2>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale)
                    : launch_attn(attn_fwd_f32_kernel<4>, B * H, threads, lds, st, (const float*)qkv, (float*)out, lse, T, H, scale);
+}
+
+extern "C" int gm3d_attention_qkv_fwd(const void* h, const void* wqkv, void* out, float* lse, void* qkv_out, int B, int T, int H,
+                                      int C, float scale, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!h || !wqkv || !out || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
+    if (dtype != GM3D_BF16 || T > 64 || C != QA_C || H * HD != C) return GM3D_EUNSUPPORTED;
+    if ((long long)B * H > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    if (B == 0) return GM3D_OK;
+    // LOOK = 1 (64 KiB of LDS, two workgroups per CU) measured best: 10.8 us at B = 64 against 13.7 / 14.2 for LOOK = 2 / 3
+    constexpr int LOOK = 1;
+    const size_t lds = (size_t)(LOOK + 1) * QA_STAGE;
+    const int total = B * H, grid = (total + 7) / 8 * 8;
+    hipStream_t st = (hipStream_t)stream;
+    return qkv_out ? launch_attn(attn_qkv_fwd_bf16_kernel<LOOK, true>, grid, 256, lds, st, (const bf16_t*)h, (const bf16_t*)wqkv,
+                                 (bf16_t*)out, lse, (bf16_t*)qkv_out, T, H, scale, total)
+                   : launch_attn(attn_qkv_fwd_bf16_kernel<LOOK, false>, grid, 256, lds, st, (const bf16_t*)h, (const bf16_t*)wqkv,
+                                 (bf16_t*)out, lse, (bf16_t*)nullptr, T, H, scale, total);
 }
 
 extern "C" int gm3d_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv,

@@ -176,6 +176,24 @@ def _attention_fwd(qkv, B, T, H, scale, out=None):
     return out, lse
 
 
+def _attention_qkv_fwd(h, wqkv, B, T, H, scale, out=None, want_qkv=False, want_lse=False):
+    """qkv projection + attention in one launch (csrc/attention.hip attn_qkv_fwd_bf16_kernel); returns (out, lse|None, qkv|None)."""
+    C = h.shape[1]
+    if out is None:
+        out = torch.empty(B * T, C, dtype=h.dtype, device=h.device)
+    lse = torch.empty(B, H, T, dtype=torch.float32, device=h.device) if want_lse else None
+    qkv = torch.empty(B * T, 3 * C, dtype=h.dtype, device=h.device) if want_qkv else None
+    _launch("gm3d_attention_qkv_fwd", {"B": B, "T": T, "H": H, "C": C, "dtype": str(h.dtype)}, lib.gm3d_attention_qkv_fwd, _ptr(h),
+            _ptr(wqkv), _ptr(out), _ptr(lse) if want_lse else None, _ptr(qkv) if want_qkv else None, B, T, H, C, float(scale),
+            _DT[h.dtype], _stream())
+    return out, lse, qkv
+
+
+def attention_qkv_supported(h, wqkv, T, H):
+    return (h.is_cuda and h.dtype == torch.bfloat16 and wqkv.dtype == torch.bfloat16 and T <= 64 and h.shape[1] == 384 == H * 64
+            and h.is_contiguous() and wqkv.is_contiguous() and tuple(wqkv.shape) == (1152, 384))
+
+
 def _attention_bwd(qkv, out, dout, lse, B, T, H, scale, dqkv=None):
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
@@ -281,6 +299,7 @@ class async_wgrad:
         return False
 
 
+FUSE_QKV_ATTENTION = True   # qkv GEMM + attention forward as one launch (bf16, 32 < T <= 64)
 PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
 
 
@@ -377,9 +396,14 @@ class TransformerStackFn(torch.autograd.Function):
                 continue
             u, h1, m1, r1 = residual_ln_fwd(res, y, bias, rs, T, posa, ln1w, ln1b, eps, adt, R, h=H1[i] if need else None)
             yield
-            qkv = _mm(h1, weight_cache.get(wqkv, adt))
-            yield
-            a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
+            Wq = weight_cache.get(wqkv, adt)
+            if FUSE_QKV_ATTENTION and T > 32 and attention_qkv_supported(h1, Wq, T, H):
+                # q|k|v never leave the CU in the no-grad (teacher) pass; with a backward to come they are written on the side
+                a, lse, qkv = _attention_qkv_fwd(h1, Wq, B, T, H, scale, out=A[i] if need else None, want_qkv=need, want_lse=need)
+            else:
+                qkv = _mm(h1, Wq)
+                yield
+                a, lse = _attention_fwd(qkv, B, T, H, scale, out=A[i] if need else None)
             yield
             p = _mm(a, weight_cache.get(wproj, adt))
             yield
@@ -388,8 +412,11 @@ class TransformerStackFn(torch.autograd.Function):
             W1 = weight_cache.get(w1, adt)
             if gemm.FUSE_GELU and gemm.supported(h2, W1):
                 # fc1 + bias + GELU in the GEMM epilogue; the pre-activation is only written when a backward follows
-                f, g = gemm.linear_gelu(h2, W1, b1, f_out=torch.empty(R, W1.shape[0], dtype=adt, device=dev) if need else None,
-                                        g_out=GG[i] if need else None)
+                fo = torch.empty(R, W1.shape[0], dtype=adt, device=dev) if need else None
+                if gemm.dma_supported(h2, W1):
+                    f, g = gemm.linear_gelu_dma(h2, W1, b1, f_out=fo, g_out=GG[i] if need else None, bm=gemm.dma_bm(R))
+                else:
+                    f, g = gemm.linear_gelu(h2, W1, b1, f_out=fo, g_out=GG[i] if need else None)
             else:
                 f = h2 @ W1.t()
                 yield
@@ -446,8 +473,10 @@ class TransformerStackFn(torch.autograd.Function):
             # 9.3-16.8 us against 11.6-21 us for the library's NN form in the step): two more transposed shadows per stack
             W1T = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 7], adt) for i in range(nblk)])  # (nblk, C, 4C)
             WQT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 2], adt) for i in range(nblk)])  # (nblk, C, 3C)
-        PGL = torch.empty(nblk, gemm.tile_rows(R) if fuse_mlp_bwd else lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32,
-                          device=dev)
+        dma_bwd = fuse_mlp_bwd and gemm.dma_supported(dh.reshape(R, C), W2T[0])
+        bm_bwd = gemm.dma_bm(R)
+        PGL = torch.empty(nblk, ((R + bm_bwd - 1) // bm_bwd if dma_bwd else gemm.tile_rows(R)) if fuse_mlp_bwd
+                          else lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32, device=dev)
         SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
         dp2_last = meta["dp"][nblk - 1][1]
         G, d_o, _ = residual_ln_bwd(dh, None, xf, mf, rf, final_w, dp2_last, T, None, True, adt, R, dy=DO[nblk - 1],
@@ -466,7 +495,8 @@ class TransformerStackFn(torch.autograd.Function):
             # mlp branch: x2 = x1 + dp2 * (g @ W2^T + b2)
             gi[10] = db2
             if fuse_mlp_bwd:
-                df = gemm.linear_gelu_bwd(d_o, W2T[i], f, b1, DF[i], PGL[i])
+                df = (gemm.linear_gelu_bwd_dma(d_o, W2T[i], f, b1, DF[i], PGL[i], bm=bm_bwd) if dma_bwd
+                      else gemm.linear_gelu_bwd(d_o, W2T[i], f, b1, DF[i], PGL[i]))
             else:
                 dg = d_o @ weight_cache.get(w2, adt)
                 df, _ = bias_gelu_bwd(dg, f, b1, adt, df=DF[i], partial=PGL[i])

@@ -46,6 +46,41 @@ def linear_tn_ring(x, w, bias=None, out=None, bm=None):
     return out
 
 
+USE_DMA = True            # K = 384 products over >= 6 column tiles of 192 on csrc/gemm_dma.hip (qkv, fc1 + GELU, fc2 input gradient)
+
+
+def dma_bm(M):
+    """Tile height of the 192-column kernel: 64 rows up to 4096 (where 128-row tiles leave CUs without a tile), else 128."""
+    return 64 if M <= 4096 else 128
+
+
+def dma_supported(x, w):
+    return USE_DMA and supported(x, w) and w.shape[0] % 192 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+
+
+def linear_tn_dma(x, w, bias=None, out=None, bm=64):
+    """linear_tn through the 192-column LDS-DMA double-buffer kernel (csrc/gemm_dma.hip): same results bit for bit; for K = 384."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_dma", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dma, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N,
+            K, x.stride(0), w.stride(0), out.stride(0), int(bm), _stream())
+    return out
+
+
+def linear_gelu_dma(x, w, bias, f_out=None, g_out=None, bm=64):
+    """linear_gelu on csrc/gemm_dma.hip (bit-identical)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if g_out is None:
+        g_out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_dma_gelu", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dma_gelu, _ptr(x), _ptr(w), _ptr(bias),
+            _ptr(f_out), _ptr(g_out), M, N, K, x.stride(0), w.stride(0), f_out.stride(0) if f_out is not None else 0,
+            g_out.stride(0), int(bm), _stream())
+    return f_out, g_out
+
+
 # LayerNorm folded into the producer / consumer GEMMs (fused.py).  OFF: measured on MI355X at B = 128 (same-box A/B, round 2) the
 # step is 2.5 % SLOWER with it (8.50 vs 8.29 ms) although 97 of 111 LayerNorm launches disappear -- the pass is dominated by the
 # fp32 residual stream (read 4 + write 4 of its 14 bytes per element), which the fusion cannot remove, only move into GEMM
@@ -108,7 +143,8 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
 
 def choose(M, N, K):
     """Which kernel runs the plain product x (M,K) @ w (N,K)^T on MI355X: "lib" (hipBLASLt through torch.mm, TunableOp table),
-    "own" (register-prefetch kernel, csrc/gemm.hip), "ring64" / "ring128" (LDS-DMA ring, csrc/gemm_ring.hip, tile height).
+    "own" (register-prefetch kernel, csrc/gemm.hip), "ring64" / "ring128" (LDS-DMA ring, csrc/gemm_ring.hip, tile height),
+    "dma64" / "dma128" (192-column LDS-DMA double buffer, csrc/gemm_dma.hip).
     From the per-shape table profiles/r02_gemm_kbench.txt (tools/gemm_kbench.py); rule: a shape stays on the library only where
     the tuned library solution is >= 5 % faster than the best hand-written form."""
     if (N, K) == (384, 384):
@@ -116,7 +152,7 @@ def choose(M, N, K):
     if N == 384 and K in (1024, 1152, 1536):            # long K, three column tiles: the ring's regime
         return "ring64" if M <= 4096 else "ring128"
     if (N, K) == (1152, 384):
-        return "ring128" if M <= 3200 else "lib"
+        return "ring128" if M <= 3200 else ("dma64" if M <= 4096 else "dma128") if USE_DMA else "lib"
     if (N, K) == (128, 256) and M >= 65536:
         return "ring128"
     return "lib"
@@ -130,6 +166,8 @@ def mm(x, w, bias=None, out=None):
         return linear_tn(x, w, bias, out)
     if how.startswith("ring"):
         return linear_tn_ring(x, w, bias, out, bm=int(how[4:]))
+    if how.startswith("dma"):
+        return linear_tn_dma(x, w, bias, out, bm=int(how[3:]))
     y = x @ w.t()
     if bias is not None:
         y = y + bias.to(y.dtype)
@@ -196,6 +234,17 @@ def linear_gelu_bwd(d_o, w2t, f, bias, df, colpart):
     N = w2t.shape[0]
     _launch("gm3d_gemm_tn_bf16_gelu_bwd", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_gelu_bwd, _ptr(d_o), _ptr(w2t), _ptr(f),
             _ptr(bias), _ptr(df), _ptr(colpart), M, N, K, d_o.stride(0), w2t.stride(0), f.stride(0), df.stride(0), _stream())
+    return df
+
+
+def linear_gelu_bwd_dma(d_o, w2t, f, bias, df, colpart, bm=64):
+    """linear_gelu_bwd on csrc/gemm_dma.hip; colpart (ceil(M / bm), hidden) f32."""
+    M, K = d_o.shape
+    N = w2t.shape[0]
+    assert colpart.shape[0] * bm >= M and colpart.shape[1] == N
+    _launch("gm3d_gemm_tn_bf16_dma_gelu_bwd", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dma_gelu_bwd, _ptr(d_o), _ptr(w2t),
+            _ptr(f), _ptr(bias), _ptr(df), _ptr(colpart), M, N, K, d_o.stride(0), w2t.stride(0), f.stride(0), df.stride(0), int(bm),
+            _stream())
     return df
 
 

@@ -102,6 +102,15 @@ int gm3d_chamfer_bwd(const float *xyz1, const float *xyz2, const int32_t *idx1, 
 int gm3d_attention_fwd(const void *qkv, void *out, float *lse, int B, int T, int H,
                        float scale, int dtype, gm3d_stream_t stream);
 
+/* The qkv projection and the attention in one launch (bf16, T <= 64, C == 384 == H*64): replaces
+ * `qkv = self.qkv(x)` + the attention above (Point-MAE_SA3D/models/Point_MAE.py:113-122) for one Block.
+ * h (B*T, C) bf16 = the normalised tokens, wqkv (3*C, C) bf16 row-major (nn.Linear weight, no bias:
+ * models_mae_learn_loss.py:907-911 qkv_bias=False).  out (B,T,C) bf16; lse (B,H,T) f32 or NULL;
+ * qkv_out (B,T,3,H,64) bf16 or NULL (written for the backward; bit-identical to gm3d_gemm_tn_bf16_ring's
+ * product, so out/lse are bit-identical to gm3d_attention_fwd on it).  GM3D_EUNSUPPORTED outside those limits. */
+int gm3d_attention_qkv_fwd(const void *h, const void *wqkv, void *out, float *lse, void *qkv_out,
+                           int B, int T, int H, int C, float scale, int dtype, gm3d_stream_t stream);
+
 /* Backward: dqkv (B,T,3,H,64) fully written from dout (B,T,H*64), qkv, out, lse. */
 int gm3d_attention_bwd(const void *qkv, const void *out, const void *dout, const float *lse,
                        void *dqkv, int B, int T, int H, float scale, int dtype,
@@ -346,6 +355,18 @@ int gm3d_gemm_tile_rows(int M);
  * flight than the register-prefetch kernel does.  bm = 64 or 128: tile height. */
 int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
                            int bm, gm3d_stream_t stream);
+/* The same products for SHORT K over many tiles (csrc/gemm_dma.hip: 64- or 128-row x 192-column tiles, LDS-DMA double buffer, two
+ * workgroups per CU): qkv, fc1, proj, the proj / fc2 input gradients (K = 384).  N % 192 == 0, K % 64 == 0, 16-byte aligned
+ * operands; results bit-identical to gm3d_gemm_tn_bf16 / gm3d_gemm_tn_bf16_ring.  bm = 64 or 128. */
+int gm3d_gemm_tn_bf16_dma(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
+                          int bm, gm3d_stream_t stream);
+/* ... with the fc1 epilogue of gm3d_gemm_tn_bf16_gelu: F (optional) = bf16(A.W^T), G = GELU(F + bias). */
+int gm3d_gemm_tn_bf16_dma_gelu(const void *A, const void *W, const float *bias, void *F, void *G, int M, int N, int K, int lda,
+                               int ldw, int ldf, int ldg, int bm, gm3d_stream_t stream);
+/* ... with the fc2 input-gradient epilogue of gm3d_gemm_tn_bf16_gelu_bwd: dF = bf16(dO.Wt^T) * GELU'(F + bias) (bit-identical);
+ * colpart (ceil(M / bm), N) f32 = per-row-tile column sums of the fp32 products. */
+int gm3d_gemm_tn_bf16_dma_gelu_bwd(const void *dO, const void *Wt, const void *F, const float *bias, void *dF, float *colpart, int M,
+                                   int N, int K, int lda, int ldw, int ldf, int lddf, int bm, gm3d_stream_t stream);
 /* dst (batch, cols, rows) = transposes of `batch` row-major (rows, cols) bf16 matrices that start src_batch_stride elements apart
  * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 64. */
 int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows, int cols, long long src_batch_stride,

@@ -176,3 +176,57 @@ def test_gemm_ring_equals_register_prefetch_kernel(M, K, N, bm):
         assert bool((out[M:] == 7.0).all())
     ref = x.float() @ w.float().t()
     assert float((want.float() - (ref + b)).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 384, 1152), (3200, 384, 1536), (8192, 384, 384), (200, 64, 192), (70, 128, 384),
+                                   (3328, 1536, 384)])
+@pytest.mark.parametrize("bm", [64, 128])
+def test_gemm_dma_equals_register_prefetch_kernel(M, K, N, bm):
+    """The 192-column LDS-DMA double-buffer form (csrc/gemm_dma.hip) multiplies in the same order as the register-prefetch kernel:
+    results bit-identical, with and without bias, rows past M untouched; so is its fc1 (GELU) epilogue."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + bm + 1)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias in (None, b):
+        if N % 128 == 0:
+            want = gemm.linear_tn(x, w, bias)
+        else:       # 192 columns: the register-prefetch kernel has no such tile; fp32 product, one rounding
+            want = None
+        out = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn_dma(x, w, bias, out=out[:M], bm=bm)
+        if want is not None:
+            assert torch.equal(out[:M], want)
+        ref = x.float() @ w.float().t() + (bias if bias is not None else 0.0)
+        assert float((out[:M].float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2
+        assert bool((out[M:] == 7.0).all())
+    if N % 128 == 0:
+        f0 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        f1 = torch.empty_like(f0)
+        _, g0 = gemm.linear_gelu(x, w, b, f_out=f0)
+        _, g1 = gemm.linear_gelu_dma(x, w, b, f_out=f1, bm=bm)
+        _, g2 = gemm.linear_gelu_dma(x, w, b, bm=bm)
+        assert torch.equal(f0, f1) and torch.equal(g0, g1) and torch.equal(g0, g2)
+
+
+@pytest.mark.parametrize("M,bm", [(4096, 64), (3200, 64), (8192, 128), (200, 64), (333, 128)])
+def test_gemm_dma_gelu_bwd_equals_register_prefetch_kernel(M, bm):
+    """fc2 input gradient + GELU backward on csrc/gemm_dma.hip: dF bit-identical to gm3d_gemm_tn_bf16_gelu_bwd; the bias-gradient
+    partials are sums of the same fp32 products over other row tiles (another order): equal after the finish within fp32 rounding."""
+    from gm3d_amd import gemm
+    K, N = 384, 1536
+    g = torch.Generator(device="cuda").manual_seed(M + bm)
+    d_o = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w2t = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    f = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    df0 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    cp0 = torch.zeros(gemm.tile_rows(M), N, device="cuda")
+    gemm.linear_gelu_bwd(d_o, w2t, f, b, df0, cp0)
+    df1 = torch.full((M + 2, N), 3.0, device="cuda", dtype=torch.bfloat16)
+    cp1 = torch.zeros((M + bm - 1) // bm, N, device="cuda")
+    gemm.linear_gelu_bwd_dma(d_o, w2t, f, b, df1[:M], cp1, bm=bm)
+    assert torch.equal(df0, df1[:M]) and bool((df1[M:] == 3.0).all())
+    s0, s1 = cp0.sum(0), cp1.sum(0)
+    assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max()) * max(1.0, M / 4096)

@@ -33,15 +33,16 @@ def bench(name, call, sets, iters=40):
     return e0.elapsed_time(e1) * 1e3 / (3 * iters)
 
 
-for (B, T, H) in ((64, 64, 6), (128, 64, 6), (128, 25, 6), (32, 65, 6), (128, 128, 6)):
-    for dt, code in ((torch.bfloat16, 1),):
-        def mk():
-            qkv = (torch.randn(B, T, 3 * H * 64, device=dev) * 0.5).to(dt)
-            return (qkv, torch.empty(B * T, H * 64, device=dev, dtype=dt), torch.empty(B, H, T, device=dev),
-                    (torch.randn(B * T, H * 64, device=dev) * 0.1).to(dt), torch.empty_like(qkv))
-        sets = [mk() for _ in range(NSET)]
-        f = bench("fwd", lambda q, o, l, do, dq: check(lib.gm3d_attention_fwd(_ptr(q), _ptr(o), _ptr(l), B, T, H, 0.125, code, _stream()), "f"), sets)
-        b = bench("bwd", lambda q, o, l, do, dq: check(lib.gm3d_attention_bwd(_ptr(q), _ptr(o), _ptr(do), _ptr(l), _ptr(dq), B, T, H, 0.125, code,
-                                                                              _stream()), "b"), sets)
-        fl = B * H * 4.0 * T * T * 64
-        print("B=%3d T=%3d  fwd %6.2f us (%5.1f TFLOP/s)   bwd %6.2f us (%5.1f TFLOP/s)" % (B, T, f, fl / f * 1e-6, b, 2.5 * fl / b * 1e-6))
+if __name__ == "__main__":
+    for (B, T, H) in ((64, 64, 6), (128, 64, 6), (128, 25, 6), (32, 65, 6), (128, 128, 6)):
+        for dt, code in ((torch.bfloat16, 1),):
+            def mk():
+                qkv = (torch.randn(B, T, 3 * H * 64, device=dev) * 0.5).to(dt)
+                return (qkv, torch.empty(B * T, H * 64, device=dev, dtype=dt), torch.empty(B, H, T, device=dev),
+                        (torch.randn(B * T, H * 64, device=dev) * 0.1).to(dt), torch.empty_like(qkv))
+            sets = [mk() for _ in range(NSET)]
+            f = bench("fwd", lambda q, o, l, do, dq: check(lib.gm3d_attention_fwd(_ptr(q), _ptr(o), _ptr(l), B, T, H, 0.125, code, _stream()), "f"), sets)
+            b = bench("bwd", lambda q, o, l, do, dq: check(lib.gm3d_attention_bwd(_ptr(q), _ptr(o), _ptr(do), _ptr(l), _ptr(dq), B, T, H, 0.125, code,
+                                                                                  _stream()), "b"), sets)
+            fl = B * H * 4.0 * T * T * 64
+            print("B=%3d T=%3d  fwd %6.2f us (%5.1f TFLOP/s)   bwd %6.2f us (%5.1f TFLOP/s)" % (B, T, f, fl / f * 1e-6, b, 2.5 * fl / b * 1e-6))

@@ -32,14 +32,20 @@ def train(fn, sets, iters=40):
     return e0.elapsed_time(e1) * 1e3 / (2 * iters)
 
 
-for M, K, N in SHAPES:
-    nset = NSET if M < 100000 else 2
-    sets = [(torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16(),
-             torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for _ in range(nset)]
-    t_lib = train(lambda x, w, o: torch.mm(x, w.t(), out=o), sets)
-    t_own = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
-    t_r64 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=64), sets)
-    t_r128 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=128), sets)
-    fl = 2.0 * M * K * N
-    print("M=%6d K=%4d N=%4d   hipBLASLt %7.1f us %5.0f TF/s   own %7.1f us %5.0f TF/s x%.2f   ring64 %7.1f us x%.2f   ring128 %7.1f us x%.2f" %
-          (M, K, N, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_lib / t_own, t_r64, t_lib / t_r64, t_r128, t_lib / t_r128))
+if __name__ == "__main__":
+    for M, K, N in SHAPES:
+        nset = NSET if M < 100000 else 2
+        sets = [(torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16(),
+                 torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for _ in range(nset)]
+        t_lib = train(lambda x, w, o: torch.mm(x, w.t(), out=o), sets)
+        t_own = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
+        t_r64 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=64), sets)
+        t_r128 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=128), sets)
+        fl = 2.0 * M * K * N
+        dma = ""
+        if N % 192 == 0:
+            t_d64 = train(lambda x, w, o: gemm.linear_tn_dma(x, w, out=o, bm=64), sets)
+            t_d128 = train(lambda x, w, o: gemm.linear_tn_dma(x, w, out=o, bm=128), sets)
+            dma = "   dma64 %7.1f us x%.2f   dma128 %7.1f us x%.2f" % (t_d64, t_lib / t_d64, t_d128, t_lib / t_d128)
+        print("M=%6d K=%4d N=%4d   hipBLASLt %7.1f us %5.0f TF/s   own %7.1f us %5.0f TF/s x%.2f   ring64 %7.1f us x%.2f   ring128 %7.1f us x%.2f" %
+              (M, K, N, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_lib / t_own, t_r64, t_lib / t_r64, t_r128, t_lib / t_r128) + dma)
