@@ -117,6 +117,13 @@ __global__ __launch_bounds__(256) void chamfer_fwd_general_kernel(const float* _
     if (live) { dist[(size_t)p * n + i] = best; idx[(size_t)p * n + i] = bi; }
 }
 
+// Zero fill by a kernel of our own, not hipMemsetAsync: a memset node captured into a hipGraph came back unexecuted / misdirected
+// on replays once the process had made other copies in between (ROCm 7.2; the gradients of the 8-point patches of Point-M2AE
+// turned into 1e34 garbage -- tools/m2ae_graph_diag.py found it), a kernel node replays like every other launch of the step.
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = 0.f;
+}
+
 // gA[i] += t, gB[idx[i]] -= t with t = 2*(A[i]-B[idx[i]])*g[i]; outputs pre-zeroed.
 __global__ void chamfer_bwd_general_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
                                            const int32_t* __restrict__ idx, const float* __restrict__ g,
@@ -174,8 +181,10 @@ extern "C" int gm3d_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
         return GM3D_OK;
     }
     if (P > 65535) return GM3D_EUNSUPPORTED;
-    if (hipMemsetAsync(gxyz1, 0, sizeof(float) * (size_t)P * n * 3, st) != hipSuccess) return GM3D_ELAUNCH;
-    if (hipMemsetAsync(gxyz2, 0, sizeof(float) * (size_t)P * m * 3, st) != hipSuccess) return GM3D_ELAUNCH;
+    const size_t na = (size_t)P * n * 3, nb = (size_t)P * m * 3;
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((na + 255) / 256 < 2048 ? (na + 255) / 256 : 2048)), dim3(256), 0, st, gxyz1, na);
+    hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)((nb + 255) / 256 < 2048 ? (nb + 255) / 256 : 2048)), dim3(256), 0, st, gxyz2, nb);
+    GM3D_CHECK_LAUNCH();
     if (grad_dist1) {
         hipLaunchKernelGGL(chamfer_bwd_general_kernel, dim3((n + 255) / 256, P), dim3(256), 0, st, xyz1, xyz2, idx1,
                            grad_dist1, n, m, gxyz1, gxyz2);

@@ -1149,7 +1149,7 @@ extern "C" int gm3d_colsum_finish_f64(const double* partial, int nrows, int pitc
 extern "C" int gm3d_colsum_partial(const void* m, int R, int C, float* partial, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!m || !partial || R < 1) return GM3D_EINVAL;
-    if (!chan_ok(C)) return GM3D_EUNSUPPORTED;
+    if (C < 8 || C % 8 || C > 2048) return GM3D_EUNSUPPORTED;          // one thread per 8 columns, at most 256 threads per row slice
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     const size_t lds = (size_t)slices_for(C) * C * 4;
     hipStream_t st = (hipStream_t)stream;

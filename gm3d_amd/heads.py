@@ -30,7 +30,8 @@ def _finish64(part, nrows, ncols):
 
 
 class LinearBiasFn(torch.autograd.Function):
-    """y = x @ W^T + b on rows; x (R,K) in adt, W (N,K[,1]) fp32 master, b (N)."""
+    """y = x @ W^T + b on rows; x (..,K), W (N,K[,1]) fp32 master, b (N) or None; computed in adt.  The bias gradient is our own
+    column-sum kernel: PyTorch's multi-block reduction is not hipGraph-replay-safe on this stack."""
 
     @staticmethod
     def forward(ctx, x, w, b, adt):
@@ -38,9 +39,9 @@ class LinearBiasFn(torch.autograd.Function):
             shp = x.shape
             x2 = x.reshape(-1, shp[-1]).to(adt).contiguous()
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
-            y = torch.addmm(weight_cache.get(b, adt), x2, W.t())
+            y = torch.addmm(weight_cache.get(b, adt), x2, W.t()) if b is not None else x2 @ W.t()
             ctx.save_for_backward(x2, w)
-            ctx.adt, ctx.shp, ctx.xdt = adt, shp, x.dtype
+            ctx.adt, ctx.shp, ctx.xdt, ctx.has_bias = adt, shp, x.dtype, b is not None
             return y.view(*shp[:-1], w.shape[0])
 
     @staticmethod
@@ -52,7 +53,7 @@ class LinearBiasFn(torch.autograd.Function):
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
             dx = (dy2 @ W).view(ctx.shp).to(ctx.xdt)
             dW = splitk_wgrad(dy2, x2).reshape(w.shape)
-            db = colsum(dy2, adt)
+            db = colsum(dy2, adt) if ctx.has_bias else None
             return dx, dW, db, None
 
 

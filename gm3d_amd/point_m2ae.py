@@ -55,9 +55,38 @@ def back_project(mask_coarse, idxs):
     return masks
 
 
+def _linear(x, weight, bias=None):
+    """x @ weight^T + bias for an nn.Linear / Conv1d(k=1) weight.  On the GPU through heads.LinearBiasFn: bf16 weight shadows
+    instead of autocast's per-call casts, the weight gradient in fp32, and the bias gradient by our own column-sum kernel -- the
+    PyTorch reduction behind nn.Linear's bias gradient comes back wrong from hipGraph replays at B = 128 (8192+ rows x 768+
+    columns; tools/m2ae_step_diag.py)."""
+    if x.is_cuda:
+        from . import heads
+        return heads.LinearBiasFn.apply(x, weight, bias, heads._adt())
+    return F.linear(x, weight.reshape(weight.shape[0], -1), bias)
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        return _linear(x, self.weight, self.bias)
+
+
+class Mlp(nn.Module):
+    """timm Mlp (same attribute names as models_mae_learn_loss.Mlp: the state-dict keys do not change)."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = Linear(in_features, hidden_features)
+        self.act = nn.GELU()
+        self.fc2 = Linear(hidden_features, in_features)
+
+    def forward(self, x):
+        return self.fc2(self.act(self.fc1(x)))
+
+
 def _lin(x, conv, bn=None, act=False):
     """Conv1d(k=1) (+ BatchNorm1d + ReLU) on a (rows, C) layout."""
-    y = F.linear(x, conv.weight.squeeze(-1), conv.bias)
+    y = _linear(x, conv.weight, conv.bias)
     if bn is not None:
         y = bn(y)
     return F.relu(y) if act else y
@@ -89,8 +118,8 @@ class MaskedAttention(nn.Module):
     def __init__(self, dim, num_heads):
         super().__init__()
         self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
-        self.qkv = nn.Linear(dim, dim * 3, bias=False)
-        self.proj = nn.Linear(dim, dim)
+        self.qkv = Linear(dim, dim * 3, bias=False)
+        self.proj = Linear(dim, dim)
 
     def forward(self, x, bits):
         qkv = self.qkv(x)
@@ -109,7 +138,7 @@ class MaskedBlock(nn.Module):
         self.attn = MaskedAttention(dim, num_heads)
         self.drop_path = M.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
         self.norm2 = nn.LayerNorm(dim)
-        self.mlp = M.Mlp(in_features=dim, hidden_features=4 * dim)
+        self.mlp = Mlp(dim, 4 * dim)
 
     def forward(self, x, bits=None):
         x = x + self.drop_path(self.attn(self.norm1(x), bits))
@@ -155,7 +184,7 @@ class TokenPropagation(nn.Module):
 
 
 def _pos_mlp(dim):
-    return nn.Sequential(nn.Linear(3, dim), nn.GELU(), nn.Linear(dim, dim))
+    return nn.Sequential(Linear(3, dim), nn.GELU(), Linear(dim, dim))
 
 
 class PointM2AE(nn.Module):
@@ -233,15 +262,25 @@ class PointM2AE(nn.Module):
         xc = torch.where(vis2.unsqueeze(-1), x2, self.mask_token.to(x2.dtype).expand(B, self.num_group, -1))
         xc = self.h_decoder[0](xc, self.decoder_pos_embeds[0](centers[2]).to(xc.dtype))
         h = self.loss_pred_head
-        y = F.leaky_relu(h[1](F.linear(xc.reshape(B * self.num_group, -1), h[0].weight.squeeze(-1), h[0].bias)), h[2].negative_slope)
-        loss_pred = F.linear(y, h[3].weight.squeeze(-1), h[3].bias).mean(dim=-1).view(B, self.num_group)
+        if xc.is_cuda:
+            # the north-star model's fused head (heads.LossPredHeadFn): its reductions are our own kernels -- the bias gradient in
+            # front of the BatchNorm (a column sum over B*64 rows of 1024) is the one PyTorch reduction of this model that comes
+            # back wrong from a hipGraph replay at B = 128 (tools/m2ae_step_diag.py)
+            from . import heads
+            meta = {"adt": heads._adt(), "training": h[1].training, "eps": h[1].eps, "momentum": h[1].momentum,
+                    "slope": h[2].negative_slope, "grad": torch.is_grad_enabled()}
+            loss_pred = heads.LossPredHeadFn.apply(xc, h[0].weight, h[0].bias, h[1].weight, h[1].bias, h[3].weight, h[3].bias,
+                                                   h[1].running_mean, h[1].running_var, h[1].num_batches_tracked, meta)
+        else:
+            y = F.leaky_relu(h[1](F.linear(xc.reshape(B * self.num_group, -1), h[0].weight.squeeze(-1), h[0].bias)), h[2].negative_slope)
+            loss_pred = F.linear(y, h[3].weight.squeeze(-1), h[3].bias).mean(dim=-1).view(B, self.num_group)
         x1 = self.encoder_norms[1](enc[1])
         x1 = torch.where(vis1.unsqueeze(-1), x1, torch.zeros((), dtype=x1.dtype, device=x1.device))
         x1 = self.token_prop[0](centers[1], centers[2], x1, xc)
         x1 = self.h_decoder[1](x1, self.decoder_pos_embeds[1](centers[1]).to(x1.dtype))
         x1 = self.decoder_norm(x1)
         G1, k1 = neighborhoods[1].shape[1], neighborhoods[1].shape[2]
-        rec = F.linear(x1, self.rec_head.weight.squeeze(-1), self.rec_head.bias).view(B, G1, k1, 3)
+        rec = _linear(x1, self.rec_head.weight, self.rec_head.bias).view(B, G1, k1, 3)
         return {"rec": rec, "loss_pred": loss_pred, "masks": masks, "group": (neighborhoods, centers, idxs), "features": x2}
 
     def forward_loss(self, rec, neighborhoods, idxs, masks):

@@ -246,7 +246,7 @@ int gm3d_pn_layer1_bwd_stats(const void *da1, const void *a1, const float *x, co
 int gm3d_colsum_finish_f64(const double *partial, int nrows, int pitch, int ncols, double *out,
                            gm3d_stream_t stream);
 
-/* partial[row][c] = column sums of a (R,C) matrix in `dtype`. */
+/* partial[row][c] = column sums of a (R,C) matrix in `dtype`; rows = gm3d_embed_partial_rows(2, R, C); C % 8 == 0, 8 <= C <= 2048. */
 int gm3d_colsum_partial(const void *m, int R, int C, float *partial, int dtype, gm3d_stream_t stream);
 
 /* out (R,C) = GELU(x (R,3) . w (C,3)^T + b): first layer + activation of pos_embed (models_mae_learn_loss.py:104-108). */

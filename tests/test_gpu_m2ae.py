@@ -83,7 +83,12 @@ def test_m2ae_forward_backward_against_oracle(epoch, seed):
         scale = max(float(g64.abs().max()), 1e-4 * gscale)
         e_prod = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
         e_cpu = float((g32.double() - g64).abs().max()) / scale
-        if e_prod > max(5e-5, 3.0 * e_cpu):
+        if float(g64.abs().max()) <= 1e-9 * gscale:
+            # an exactly zero gradient (a bias in front of a BatchNorm): what either side reports is the rounding residue of a
+            # sum of cancelling terms, whose size depends on the summation order only -- bar: 1e-7 of the largest gradient
+            if e_prod > 1e-3:
+                bad[name] = (e_prod, e_cpu)
+        elif e_prod > max(5e-5, 3.0 * e_cpu):
             bad[name] = (e_prod, e_cpu)
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
     assert n > 150
@@ -106,3 +111,55 @@ def test_m2ae_bf16_step_runs_and_learns():
         assert all(float(o[k]) == float(o[k]) for k in ("loss", "loss_learn", "grad_norm"))
     assert not torch.equal(model.rec_head.weight, before)
     assert losses[-1] < losses[0]
+
+
+def test_m2ae_step_replays_like_eager_at_full_batch():
+    """The whole Point-M2AE step (clip + AdamW + EMA included) captured as a hipGraph and replayed on fresh inputs at the bench's
+    B = 128 -- the size at which PyTorch's own bias-gradient reductions came back non-finite from the second replay on
+    (tools/m2ae_step_diag.py; the model's Linear layers now use our column-sum kernel).  A twin model stepping eagerly on the same
+    inputs must see the same losses within the bf16 step's run-to-run band (index_add / scatter atomics make even eager vs eager
+    differ in the last bf16 digits)."""
+    from types import SimpleNamespace
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import point_m2ae as P
+    B = 128
+    args = SimpleNamespace(bf16=True, epochs=300)
+    pool = [clouds.gaussian(B, 2048, seed=900 + i).cuda() for i in range(5)]
+    noise = [torch.rand(B, 64, generator=torch.Generator().manual_seed(40 + i)).cuda() for i in range(5)]
+    twins = []
+    for _ in range(2):
+        torch.manual_seed(11)
+        m = P.PointM2AE().cuda().train()
+        for mod in m.modules():
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        ema = E.ModelEma(m, 0.999)
+        twins.append((m, ema, E.build_optimizer(m, lr=1e-3, flat=True, model_ema=ema)))
+    (ma, ea, oa), (mb, eb, ob) = twins
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):                      # the eager iterations before a capture: optimizer steps on both twins
+            P.pretrain_step(ma, ea, oa, pool[i].clone(), 100, args, mask_noise=noise[i], augment=False)
+            P.pretrain_step(mb, eb, ob, pool[i].clone(), 100, args, mask_noise=noise[i], augment=False)
+        torch.cuda.synchronize()
+        static_in, static_noise = pool[0].clone(), noise[0].clone()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = P.pretrain_step(mb, eb, ob, static_in, 100, args, mask_noise=static_noise, augment=False)
+    torch.cuda.current_stream().wait_stream(side)
+    for i in range(2, 5):
+        want = P.pretrain_step(ma, ea, oa, pool[i].clone(), 100, args, mask_noise=noise[i], augment=False)
+        static_in.copy_(pool[i])
+        static_noise.copy_(noise[i])
+        g.replay()
+        torch.cuda.synchronize()
+        for k in ("loss_chfr", "loss_learn", "grad_norm"):
+            a, b = float(want[k]), float(out[k])
+            assert b == b and abs(b) != float("inf"), (i, k, b)
+            assert abs(a - b) <= 5e-2 * abs(a), (i, k, a, b)
+        assert bool(torch.isfinite(ob.P).all()) and bool(torch.isfinite(ob.E).all())
+    # early AdamW steps move every weight by about lr whatever the size of its gradient: where a gradient is rounding noise
+    # (exact zeros) the twins may step in opposite directions, 2 lr apart per step -- 5 steps, lr 1e-3
+    assert float((oa.P - ob.P).abs().max()) <= 1.2e-2
+    assert float((oa.P - ob.P).abs().mean()) <= 2e-4
