@@ -46,6 +46,8 @@ def algorithmic(name, meta):
         return "hbm", meta["P"] * ((meta["n"] + meta["m"]) * (12 + 4 + 4 + 12)), "B"
     if name == "gm3d_attention_fwd":  # QK^T + PV: 4*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
+    if name == "gm3d_attention_qkv_fwd":  # the head's q|k|v projection (T x 192 x C) + QK^T + PV per (b,h)
+        return "mfma", meta["B"] * meta["H"] * (2.0 * meta["T"] * 192 * meta["C"] + 4.0 * meta["T"] ** 2 * 64), "FLOP"
     if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
     if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMMs (+ epilogues; register-prefetch and LDS-DMA ring forms): 2*M*N*K flop
@@ -93,6 +95,10 @@ def pmc_traffic(kernel, dtype, metas=()):
         return None
     if kernel == "gm3d_gemm_tn_bf16_ring":
         rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_ring_kernel")]
+    elif kernel.startswith("gm3d_gemm_tn_bf16_dma"):
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_dma_kernel")]
+    elif kernel == "gm3d_attention_qkv_fwd":
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::attn_qkv_fwd_bf16_kernel")]
     elif kernel == "gm3d_gemm_nt_bf16":
         rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_nt_bf16_kernel")]
     elif kernel.startswith("gm3d_gemm_tn_bf16"):
