@@ -173,3 +173,50 @@ def test_scale_translate_kernel_equals_op_chain():
     want = aug(pc.clone(), draws=(scale, shift))
     assert torch.equal(got, want)
     assert float(scale.min()) >= 2.0 / 3.0 - 1e-6 and float(scale.max()) <= 1.5 + 1e-6 and float(shift.abs().max()) <= 0.2 + 1e-6
+
+
+def test_chamfer_general_backward_survives_graph_replay(gops):
+    """The general-shape Chamfer backward (the 8-point patches of Point-M2AE) zero-fills its outputs before an atomic scatter.  With
+    hipMemsetAsync as the fill, a captured graph came back with 1e34-sized garbage once the process had made other host-to-device
+    copies after the capture (found by tools/m2ae_graph_diag.py): the fill is a kernel of the C ABI now.  Replay after such copies
+    must equal the eager result bit for bit (the atomics add one term per slot and direction: order cannot matter)."""
+    P, n = 4096, 8
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(P, n, 3, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(P, n, 3, generator=g).cuda()
+    w = torch.rand(P, n, generator=g).cuda()
+
+    def fb():
+        a.grad = None
+        d1, d2, _, _ = gops.chamfer(a, b)
+        ((d1 + d2) * w).sum().backward()
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fb()
+        fb()
+        torch.cuda.synchronize()
+        want = a.grad.clone()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=side):
+            fb()
+    torch.cuda.current_stream().wait_stream(side)
+    junk = [torch.nn.Linear(384, 1536).cuda() for _ in range(40)]           # host-to-device copies + allocations after the capture
+    junk += [torch.full((1 << 18,), float("nan"), device="cuda") for _ in range(16)]
+    for _ in range(3):
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(a.grad, want)
+    del junk
+
+
+@pytest.mark.parametrize("R,C", [(8192, 1536), (300, 2048), (4096, 24), (65536, 96)])
+def test_colsum_wide(R, C):
+    """gm3d_colsum_partial + finish up to 2048 columns (the bias gradients of Point-M2AE's Linear layers) against an fp64 sum."""
+    from gm3d_amd import embed
+    for dt in (torch.bfloat16, torch.float32):
+        m = torch.randn(R, C, generator=torch.Generator().manual_seed(R + C)).cuda().to(dt)
+        got = embed.colsum(m, dt)
+        want = m.double().sum(0)
+        assert float((got.double() - want).abs().max()) <= 2e-6 * float(m.double().abs().sum(0).max())
