@@ -25,6 +25,8 @@ SIGNATURES = {
     "gm3d_knn_group": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp],
     "gm3d_chamfer_fwd": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gm3d_chamfer_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_patch_chamfer_loss_fwd": [_vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _vp],
+    "gm3d_patch_chamfer_loss_bwd": [_vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp],
     "gm3d_attention_fwd": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_qkv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],

@@ -87,6 +87,111 @@ __global__ __launch_bounds__(256) void chamfer32_bwd_kernel(const float* __restr
     out[0] = ax; out[1] = ay; out[2] = az;
 }
 
+// ------------------------------------------------------------------ the pre-training loss on the masked patches, fused
+// forward_loss of the north-star model (models_mae_learn_loss.py:384-412): target = neighborhood[mask] -> (B*M,32,3), pred ->
+// (B*M,32,3) cast to fp32, per-point Chamfer (d1 + d2), `matrix` = mean over the 32 points, Chamfer_mean = mean of everything.
+// As separate ops that is a gather, a contiguous copy, a cast, the Chamfer kernel, an add and two means (and their five backward
+// launches) around 15 us of work; here: ONE wave per masked patch reads its predicted points straight from the decoder head's
+// output (any float type, batch-strided view) and its target patch through the id list, keeps the 32x32 pair tile in readlanes like
+// chamfer32_fwd_kernel (identical distance arithmetic and argmin rule), and writes the patch mean; a one-block kernel finishes the
+// scalar.  The backward writes d(mean)/d(pred) in pred's type from the saved argmins.
+template <class T>
+__global__ __launch_bounds__(256) void patch_loss_fwd_kernel(const T* __restrict__ pred, size_t pred_bstride,
+                                                             const float* __restrict__ target, const long long* __restrict__ ids,
+                                                             size_t ids_bstride, int B, int Tn, int M, float* __restrict__ matrix,
+                                                             int32_t* __restrict__ i1, int32_t* __restrict__ i2) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= B * M) return;  // wave-uniform
+    const int b = p / M, m = p - b * M;
+    const bool first = lane < 32;
+    const int l = lane & 31;
+    float mx, my, mz;
+    if (first) {
+        const T* pp = pred + (size_t)b * pred_bstride + (size_t)m * 96 + l * 3;
+        mx = (float)pp[0]; my = (float)pp[1]; mz = (float)pp[2];
+    } else {
+        const long long id = ids[(size_t)b * ids_bstride + m];
+        const float* tp = target + (((size_t)b * Tn + (size_t)id) * 32 + l) * 3;
+        mx = tp[0]; my = tp[1]; mz = tp[2];
+    }
+    float best = 0.f;
+    int bi = 0;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const float ox = first ? rl(mx, 32 + t) : rl(mx, t);
+        const float oy = first ? rl(my, 32 + t) : rl(my, t);
+        const float oz = first ? rl(mz, 32 + t) : rl(mz, t);
+        const float d = sqdist3(mx, my, mz, ox, oy, oz);
+        if (t == 0 || d < best) { best = d; bi = t; }
+    }
+    const size_t o = (size_t)p * 32 + l;
+    if (first) i1[o] = bi; else i2[o] = bi;
+    float s = __fadd_rn(best, __shfl(best, lane ^ 32));          // d1[l] + d2[l] on both halves
+#pragma unroll
+    for (int w = 16; w > 0; w >>= 1) s = __fadd_rn(s, __shfl_xor(s, w));
+    if (lane == 0) matrix[p] = s * (1.0f / 32.0f);
+}
+
+// mean of n values, one block, fixed order (thread-strided partial sums, then a tree)
+__global__ __launch_bounds__(256) void mean_small_kernel(const float* __restrict__ v, int n, float* __restrict__ out) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += v[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void patch_loss_bwd_kernel(const T* __restrict__ pred, size_t pred_bstride,
+                                                             const float* __restrict__ target, const long long* __restrict__ ids,
+                                                             size_t ids_bstride, const int32_t* __restrict__ i1,
+                                                             const int32_t* __restrict__ i2, const float* __restrict__ gmean, int B,
+                                                             int Tn, int M, T* __restrict__ dpred) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= B * M) return;
+    const int b = p / M, m = p - b * M;
+    const bool first = lane < 32;
+    const int l = lane & 31;
+    float mx, my, mz;
+    if (first) {
+        const T* pp = pred + (size_t)b * pred_bstride + (size_t)m * 96 + l * 3;
+        mx = (float)pp[0]; my = (float)pp[1]; mz = (float)pp[2];
+    } else {
+        const long long id = ids[(size_t)b * ids_bstride + m];
+        const float* tp = target + (((size_t)b * Tn + (size_t)id) * 32 + l) * 3;
+        mx = tp[0]; my = tp[1]; mz = tp[2];
+    }
+    // d mean / d (d1 | d2)[point] = (g / (B M)) / 32: the two divisions autograd makes for mean() of mean(dim=-1)
+    const float g = (gmean[0] / (float)(B * M)) / 32.0f;
+    const size_t o = (size_t)p * 32 + l;
+    const int j = first ? i1[o] : i2[o];
+    const int src = first ? 32 + j : j;
+    const float ox = __shfl(mx, src), oy = __shfl(my, src), oz = __shfl(mz, src);
+    const float tx = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(mx, ox)), g);
+    const float ty = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(my, oy)), g);
+    const float tz = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(mz, oz)), g);
+    float ax = tx, ay = ty, az = tz;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) {
+        const int sj = first ? __builtin_amdgcn_readlane(j, 32 + t) : __builtin_amdgcn_readlane(j, t);
+        const float sx = first ? rl(tx, 32 + t) : rl(tx, t);
+        const float sy = first ? rl(ty, 32 + t) : rl(ty, t);
+        const float sz = first ? rl(tz, 32 + t) : rl(tz, t);
+        if (sj == l) { ax = __fsub_rn(ax, sx); ay = __fsub_rn(ay, sy); az = __fsub_rn(az, sz); }
+    }
+    if (first) {
+        T* out = dpred + (size_t)p * 96 + l * 3;
+        out[0] = (T)ax; out[1] = (T)ay; out[2] = (T)az;
+    }
+}
+
 // General shapes: thread per point of A, B streamed through LDS in tiles.
 constexpr int CH_TILE = 1024;
 __global__ __launch_bounds__(256) void chamfer_fwd_general_kernel(const float* __restrict__ A,
@@ -195,5 +300,46 @@ extern "C" int gm3d_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
                            grad_dist2, m, n, gxyz2, gxyz1);
         GM3D_CHECK_LAUNCH();
     }
+    return GM3D_OK;
+}
+
+#define GM3D_CH_DISPATCH(dtype, CALL_BF16, CALL_F32) \
+    do { if ((dtype) == GM3D_BF16) { CALL_BF16; } else { CALL_F32; } } while (0)
+
+extern "C" int gm3d_patch_chamfer_loss_fwd(const void* pred, long long pred_bstride, const float* target, const long long* ids,
+                                           long long ids_bstride, int B, int T, int M, float* matrix, int32_t* idx1, int32_t* idx2,
+                                           float* mean_out, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!pred || !target || !ids || !matrix || !idx1 || !idx2 || !mean_out || B < 1 || T < 1 || M < 1 || M > T) return GM3D_EINVAL;
+    if (pred_bstride < (long long)M * 96 || ids_bstride < M) return GM3D_EINVAL;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if ((long long)B * M > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * M;
+    GM3D_CH_DISPATCH(dtype,
+                  hipLaunchKernelGGL(patch_loss_fwd_kernel<bf16_t>, dim3((P + 3) / 4), dim3(256), 0, st, (const bf16_t*)pred,
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, B, T, M, matrix, idx1, idx2),
+                  hipLaunchKernelGGL(patch_loss_fwd_kernel<float>, dim3((P + 3) / 4), dim3(256), 0, st, (const float*)pred,
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, B, T, M, matrix, idx1, idx2));
+    hipLaunchKernelGGL(mean_small_kernel, dim3(1), dim3(256), 0, st, matrix, P, mean_out);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_patch_chamfer_loss_bwd(const void* pred, long long pred_bstride, const float* target, const long long* ids,
+                                           long long ids_bstride, const int32_t* idx1, const int32_t* idx2, const float* gmean, int B,
+                                           int T, int M, void* dpred, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!pred || !target || !ids || !idx1 || !idx2 || !gmean || !dpred || B < 1 || T < 1 || M < 1 || M > T) return GM3D_EINVAL;
+    if (pred_bstride < (long long)M * 96 || ids_bstride < M) return GM3D_EINVAL;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int P = B * M;
+    GM3D_CH_DISPATCH(dtype,
+                  hipLaunchKernelGGL(patch_loss_bwd_kernel<bf16_t>, dim3((P + 3) / 4), dim3(256), 0, st, (const bf16_t*)pred,
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (bf16_t*)dpred),
+                  hipLaunchKernelGGL(patch_loss_bwd_kernel<float>, dim3((P + 3) / 4), dim3(256), 0, st, (const float*)pred,
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (float*)dpred));
+    GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

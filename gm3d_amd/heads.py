@@ -219,6 +219,50 @@ class _RankLoss(torch.autograd.Function):
         return (dp * (g / tot[1])).to(ctx.pdt), None
 
 
+class PatchChamferLossFn(torch.autograd.Function):
+    """forward_loss of the north-star model on the masked patches in one pass (csrc/chamfer.hip patch_loss_*): pred (B,M,96) -- a
+    batch-strided view of the decoder head's (B,L,96) output is taken as it is --, target (B,T,32,3) f32, mask_ids (B,M) int64
+    -> (Chamfer_mean (), matrix (B,M) f32).  Only Chamfer_mean carries a gradient (the engine detaches `matrix`: it is the teacher's
+    ranking target, P/engine_pretrain.py:156-171)."""
+
+    @staticmethod
+    def forward(ctx, pred, target, mask_ids):
+        B, M, _ = pred.shape
+        T = target.shape[1]
+        dev = pred.device
+        matrix = torch.empty(B, M, dtype=torch.float32, device=dev)
+        i1 = torch.empty(B * M, 32, dtype=torch.int32, device=dev)
+        i2 = torch.empty(B * M, 32, dtype=torch.int32, device=dev)
+        mean = torch.empty((), dtype=torch.float32, device=dev)
+        _launch("gm3d_patch_chamfer_loss_fwd", {"B": B, "M": M, "dtype": str(pred.dtype)}, lib.gm3d_patch_chamfer_loss_fwd, _ptr(pred),
+                pred.stride(0), _ptr(target), _ptr(mask_ids), mask_ids.stride(0), B, T, M, _ptr(matrix), _ptr(i1), _ptr(i2), _ptr(mean),
+                _DT[pred.dtype], _stream())
+        ctx.save_for_backward(pred, target, mask_ids, i1, i2)
+        ctx.mark_non_differentiable(matrix)
+        return mean, matrix
+
+    @staticmethod
+    def backward(ctx, g, _gm):
+        pred, target, mask_ids, i1, i2 = ctx.saved_tensors
+        B, M, _ = pred.shape
+        g = g.detach().reshape(1).float().contiguous()
+        dpred = torch.empty(B, M, 96, dtype=pred.dtype, device=pred.device)
+        _launch("gm3d_patch_chamfer_loss_bwd", {"B": B, "M": M, "dtype": str(pred.dtype)}, lib.gm3d_patch_chamfer_loss_bwd, _ptr(pred),
+                pred.stride(0), _ptr(target), _ptr(mask_ids), mask_ids.stride(0), _ptr(i1), _ptr(i2), _ptr(g), B, target.shape[1], M,
+                _ptr(dpred), _DT[pred.dtype], _stream())
+        return dpred, None, None
+
+
+FUSED_PATCH_LOSS = True
+
+
+def patch_chamfer_loss_supported(pred, target, mask_ids):
+    return (FUSED_PATCH_LOSS and pred.is_cuda and pred.dim() == 3 and pred.shape[-1] == 96 and pred.stride(2) == 1 and pred.stride(1) == 96
+            and pred.dtype in _DT and target.dtype == torch.float32 and target.is_contiguous() and tuple(target.shape[2:]) == (32, 3)
+            and mask_ids is not None and mask_ids.dtype == torch.int64 and mask_ids.stride(1) == 1
+            and mask_ids.shape == pred.shape[:2] and not target.requires_grad)
+
+
 def rank_loss(pred, target):
     return _RankLoss.apply(pred, target)
 

@@ -510,6 +510,11 @@ class MaskedAutoencoderViT(nn.Module):
         M = pred.shape[1]
         if mask_ids is None:
             _, mask_ids = split_ids(mask, t - M)
+        if FUSED_HEADS:
+            from . import heads
+            if heads.patch_chamfer_loss_supported(pred, target, mask_ids):       # gather + cast + Chamfer + both means: one pass
+                mean, matrix = heads.PatchChamferLossFn.apply(pred, target, mask_ids)
+                return {"MSE_mean": mean.detach() * 0.0, "Chamfer_mean": mean, "matrix": matrix, "MSE_zero": True}
         target = take(target, mask_ids).reshape(-1, n, D).to(torch.float32)
         pred = pred.reshape(-1, n, D).to(torch.float32)
         loss = self.loss_func(pred, target).reshape(N, -1, n)

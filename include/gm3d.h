@@ -116,6 +116,20 @@ int gm3d_attention_bwd(const void *qkv, const void *out, const void *dout, const
                        void *dqkv, int B, int T, int H, float scale, int dtype,
                        gm3d_stream_t stream);
 
+/* The pre-training loss on the masked patches in one pass (models_mae_learn_loss.py:384-412 forward_loss: target[mask] gather, fp32
+ * cast, ChamferDistanceL2 per point (d1 + d2), mean over the 32 points -> `matrix`, mean of everything -> Chamfer_mean).
+ * pred: the decoder head's output for the M masked tokens of each cloud, (B, M, 96) in `dtype` with batch stride pred_bstride
+ * elements (a view of the (B, L, 96) output is fine); target (B, T, 32, 3) f32 = the neighbourhoods; ids (B, M) int64 = the masked
+ * group ids (row stride ids_bstride).  Out: matrix (B, M) f32, idx1 / idx2 (B*M, 32) int32 (argmins, for the backward), mean_out (1)
+ * f32.  Distances and argmins as gm3d_chamfer_fwd (bit-identical); the means are summed in a fixed order. */
+int gm3d_patch_chamfer_loss_fwd(const void *pred, long long pred_bstride, const float *target, const long long *ids,
+                                long long ids_bstride, int B, int T, int M, float *matrix, int32_t *idx1, int32_t *idx2,
+                                float *mean_out, int dtype, gm3d_stream_t stream);
+/* dpred (B, M, 96) contiguous in `dtype` = gmean[0] * d(mean_out)/d(pred). */
+int gm3d_patch_chamfer_loss_bwd(const void *pred, long long pred_bstride, const float *target, const long long *ids,
+                                long long ids_bstride, const int32_t *idx1, const int32_t *idx2, const float *gmean, int B, int T,
+                                int M, void *dpred, int dtype, gm3d_stream_t stream);
+
 /* ---- Row-wise fused passes around the transformer-block GEMMs (gm3d_amd/csrc/rowops.hip) ------------
  * Together they restate timm-0.4.5 Block.forward (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146)
  * as driven by TransformerEncoder/Decoder.forward (models_mae_learn_loss.py:914-917,984-990).

@@ -150,3 +150,36 @@ def test_token_assemble(dtype, V):
     assert torch.equal(got[3], tok.grad)
     tol = 0.0 if dtype == torch.float32 else 2.0 ** -7 * float(pos.grad.abs().max())     # bf16: the module path sums in another order
     assert float((got[4].float() - pos.grad.float()).abs().max()) <= tol + 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,M", [(4, 39), (128, 39), (3, 1), (2, 64)])
+def test_patch_chamfer_loss_equals_the_op_chain(dtype, B, M):
+    """heads.PatchChamferLossFn (gather + cast + Chamfer + both means in one pass, csrc/chamfer.hip) against the op chain of
+    forward_loss (models_mae_learn_loss.py:384-412 restated with the separate kernels): per-patch losses and the gradient agree to
+    fp32 summation order (the distances and argmins are the same arithmetic), also on a batch-strided view of the head's output."""
+    from gm3d_amd import heads, ops
+    from gm3d_amd import models_mae_learn_loss as M_
+    L = 64
+    g = torch.Generator().manual_seed(B * 7 + M)
+    pix = (torch.randn(B, L, 96, generator=g) * 0.3).cuda().to(dtype).requires_grad_(True)
+    target = (torch.randn(B, L, 32, 3, generator=g) * 0.3).cuda()
+    order = torch.stack([torch.randperm(L, generator=g) for _ in range(B)]).cuda()
+    mask_ids = order[:, L - M:]
+    pred = pix[:, L - M:]
+    assert heads.patch_chamfer_loss_supported(pred, target, mask_ids)
+    mean, matrix = heads.PatchChamferLossFn.apply(pred, target, mask_ids)
+    (mean * 3.0).backward()
+    got_g = pix.grad.clone()
+    pix.grad = None
+    tg = M_.take(target, mask_ids).reshape(-1, 32, 3)
+    loss = ops.ChamferDistanceL2()(pix[:, L - M:].reshape(-1, 32, 3).to(torch.float32), tg).reshape(B, -1, 32)
+    want_matrix = loss.mean(dim=-1)
+    want_mean = want_matrix.mean()
+    (want_mean * 3.0).backward()
+    assert float((matrix - want_matrix).abs().max()) <= 2e-6 * float(want_matrix.abs().max())
+    assert abs(float(mean) - float(want_mean)) <= 2e-6 * abs(float(want_mean))
+    scale = float(pix.grad.float().abs().max())
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((got_g.float() - pix.grad.float()).abs().max()) <= tol * scale
+    assert float(got_g[:, :L - M].abs().max()) == 0.0 if M < L else True
