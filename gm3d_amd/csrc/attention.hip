@@ -744,6 +744,7 @@ extern "C" int gm3d_attention_qkv_fwd(const void* h, const void* wqkv, void* out
     using namespace gm3d;
     if (!h || !wqkv || !out || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
     if (dtype != GM3D_BF16 || T > 64 || C != QA_C || H * HD != C) return GM3D_EUNSUPPORTED;
+    if ((((size_t)h | (size_t)wqkv | (size_t)out | (size_t)qkv_out) & 15)) return GM3D_EUNSUPPORTED;       // 16-byte LDS-DMA / row stores
     if ((long long)B * H > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     if (B == 0) return GM3D_OK;
     // LOOK = 1 (64 KiB of LDS, two workgroups per CU) measured best: 10.8 us at B = 64 against 13.7 / 14.2 for LOOK = 2 / 3

@@ -191,7 +191,8 @@ def _attention_qkv_fwd(h, wqkv, B, T, H, scale, out=None, want_qkv=False, want_l
 
 def attention_qkv_supported(h, wqkv, T, H):
     return (h.is_cuda and h.dtype == torch.bfloat16 and wqkv.dtype == torch.bfloat16 and T <= 64 and h.shape[1] == 384 == H * 64
-            and h.is_contiguous() and wqkv.is_contiguous() and tuple(wqkv.shape) == (1152, 384))
+            and h.is_contiguous() and wqkv.is_contiguous() and tuple(wqkv.shape) == (1152, 384)
+            and h.data_ptr() % 16 == 0 and wqkv.data_ptr() % 16 == 0)
 
 
 def _attention_bwd(qkv, out, dout, lse, B, T, H, scale, dqkv=None):
