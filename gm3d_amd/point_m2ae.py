@@ -20,7 +20,8 @@ scoring (P/engine_pretrain.py:86-171) put on the COARSEST tokens.  Parity is aga
 
 Kernels: gm3d_fps / gm3d_knn_group per level, gm3d_knn (3-NN propagation), gm3d_attention_masked_fwd/bwd (T up to 512, head_dim
 16/32/64, bitset mask), gm3d_attention_* (unmasked 64-token stage), gm3d_chamfer_*, gm3d_mask_select, gm3d_rank_loss.  The
-Linear / LayerNorm / BatchNorm layers of the 96- and 192-wide levels are PyTorch modules (library GEMMs).
+level-0 token embed runs on embed.EmbedFn, every Linear on heads.LinearBiasFn; LayerNorm and the deeper levels' BatchNorm are
+PyTorch modules.
 """
 import torch
 import torch.nn as nn
@@ -29,6 +30,9 @@ import torch.nn.functional as F
 from . import models_mae_learn_loss as M
 from . import ops
 from .hierarchical_group import HierarchicalGroup
+
+
+FUSED_EMBED0 = True
 
 
 def radius_mask(center, radius):
@@ -233,7 +237,18 @@ class PointM2AE(nn.Module):
         outs, prev = [], None
         for i in range(3):
             if i == 0:
-                tok = self.token_embed[0](neighborhoods[0])
+                from . import heads
+                if neighborhoods[0].is_cuda and FUSED_EMBED0 and heads._adt() == torch.bfloat16:
+                    # the level-0 embed has Point-MAE's layer structure (xyz in, 16-point groups): the north-star model's fused
+                    # mini-PointNet (embed.EmbedFn: analytic layer-1 statistics, BatchNorm folded into streaming passes, no
+                    # concatenation, fp32 weight gradients) -- 1 M rows here, the largest tensors of the step: 53.5 -> 40.1 ms.
+                    # Throughput (bf16) mode only: in fp32 the per-op modules stay, which is the path tests/test_gpu_m2ae.py pins
+                    # against the oracle (the fused node's fp32 BatchNorm sums are two-stage fp32 -- within 3e-5 of the modules,
+                    # tests/test_gpu_embed.py, but the oracle test's fp64 criterion for weights in front of a BatchNorm is tighter)
+                    from . import embed
+                    tok = embed.run_embed(self.token_embed[0], neighborhoods[0])
+                else:
+                    tok = self.token_embed[0](neighborhoods[0])
             else:
                 B, G, k = idxs[i].shape
                 tok = self.token_embed[i](M.take(prev, idxs[i].reshape(B, G * k)).view(B, G, k, -1))

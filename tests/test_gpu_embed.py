@@ -132,3 +132,51 @@ def test_group_select_maps():
     want_inv[want_sel.long()] = torch.arange(B * V, dtype=torch.int32, device="cuda")
     assert torch.equal(inv, want_inv)
     assert lib.gm3d_group_select_maps(_ptr(order), V - 1, B, V, G, _ptr(sel), _ptr(inv), _stream()) != 0      # pitch < V
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_embed_at_point_m2ae_level0_sizes(bf16):
+    """The fused node on Point-M2AE's level-0 token embed (gm3d_amd/point_m2ae.TokenEmbed(3, 96): 16-point groups, 512 groups per
+    cloud, a 96-wide output -- max-pools outside the GEMM epilogue, narrow last conv) against the same module run op by op."""
+    from gm3d_amd import embed, point_m2ae as P
+    torch.manual_seed(5)
+    base = P.TokenEmbed(3, 96).cuda().train()
+    with torch.no_grad():
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    nb = torch.randn(2, 512, 16, 3, device="cuda") * 0.2
+    w = torch.randn(2, 512, 96, device="cuda")
+
+    def run(fused, amp):
+        enc = copy.deepcopy(base)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            tok = embed.run_embed(enc, nb) if fused else enc(nb)
+            (tok.float() * w).sum().backward()
+        return (tok.detach().double(), {k: p.grad.detach().double() for k, p in enc.named_parameters()},
+                {k: b.detach().double() for k, b in enc.named_buffers()})
+
+    ref_tok, ref_g, ref_b = run(False, False)
+    gnorm = sum(float(v.pow(2).sum()) for v in ref_g.values()) ** 0.5
+    tok, g, b = run(True, bf16)
+    if not bf16:
+        # 16,384 rows in front of every BatchNorm: the weight gradients there are small differences of large sums, and the fp32
+        # op chain is itself only good to ~1e-4 of the largest entry -- the yardstick is the same module in fp64
+        enc64 = copy.deepcopy(base).cpu().double()           # on the CPU: the module's plain F.linear / BatchNorm path
+        tok64 = enc64(nb.cpu().double())
+        (tok64 * w.cpu().double()).sum().backward()
+        g64 = {k: p.grad.detach().cuda() for k, p in enc64.named_parameters()}
+        tok64 = tok64.detach().cuda()
+        assert _err(tok, tok64) <= 1e-5 * float(tok64.abs().max())
+        for k in ref_g:
+            e_f, e_m = _err(g[k], g64[k]), _err(ref_g[k], g64[k])
+            assert e_f <= max(2.0 * e_m, 3e-5 * float(g64[k].abs().max()) + 1e-6 * gnorm), (k, e_f, e_m)
+        for k in ref_b:
+            assert _err(b[k], ref_b[k]) <= 1e-5 * float(ref_b[k].abs().max()) + 1e-7, k
+    else:
+        mtok, mg, mb = run(False, True)
+        assert _err(tok, ref_tok) <= 2 * _err(mtok, ref_tok) + 2e-2 * float(ref_tok.abs().max())
+        for k in ref_g:
+            assert _err(g[k], ref_g[k]) <= 2 * _err(mg[k], ref_g[k]) + 1e-3 * float(ref_g[k].abs().max()) + 1e-6 * gnorm, k
+        for k in ref_b:
+            assert _err(b[k], ref_b[k]) <= 2 * _err(mb[k], ref_b[k]) + 1e-3 * float(ref_b[k].abs().max()) + 1e-6, k
