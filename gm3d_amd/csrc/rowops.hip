@@ -145,7 +145,137 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(const float* __res
     }
 }
 
-// Backward of the above for one LayerNorm site.
+// ------------------------------------------------------------------ plain LayerNorm of any width C <= 512, C % 4 == 0
+// nn.LayerNorm of the Point-M2AE levels (96 / 192 / 384 wide; Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99) and any other
+// (rows, C) site: h = (x - mean) * rstd * gamma + beta, statistics in fp32 over the row (two passes over registers), x and h in T.
+// Half a wave per row like residual_ln_fwd_kernel; lane hl owns the quads at columns 4 hl + 128 i (i < NQ) that lie below C.
+template <class T, int NQ>
+__global__ __launch_bounds__(256) void ln_plain_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, T* __restrict__ h,
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int R, int C) {
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int stride = gridDim.x * 8;
+    const float invc = 1.0f / (float)C;
+    for (int rb = wbase; rb < R; rb += stride) {
+        const bool valid = rb + half < R;
+        const int r = valid ? rb + half : R - 1;
+        const size_t base = (size_t)r * C;
+        float v[NQ][4];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = 4 * hl + 128 * i;
+            if (c < C) Quad<T>::load(x + base + c, v[i]);
+            else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+        const float mu = half_sum(s, lane) * invc;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i)
+            if (4 * hl + 128 * i < C) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mu; q += d * d; }
+            }
+        const float rsd = rsqrtf(half_sum(q, lane) * invc + eps);
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = 4 * hl + 128 * i;
+            if (c < C) {
+                float g[4], b[4], o[4];
+                Quad<float>::load(gamma + c, g);
+                Quad<float>::load(beta + c, b);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mu) * rsd * g[j] + b[j];
+                if (valid) Quad<T>::store(h + base + c, o);
+            }
+        }
+        if (hl == 0 && valid) { mean[r] = mu; rstd[r] = rsd; }
+    }
+}
+
+// Backward: g = dh * gamma, dx = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)); partial[block][0][c] = sum_rows dh * xhat
+// (dgamma), partial[block][1][c] = sum_rows dh (dbeta), finished by gm3d_colsum_finish over the blocks.
+template <class T, int NQ>
+__global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ x,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                           const float* __restrict__ gamma, T* __restrict__ dx,
+                                                           float* __restrict__ partial, int R, int C) {
+    __shared__ float red[8][2 * 512];
+    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, slot = (threadIdx.x >> 6) * 2 + half;
+    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    const int stride = gridDim.x * 8;
+    const float invc = 1.0f / (float)C;
+    float sg[NQ][4], sb[NQ][4], gm[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int c = 4 * hl + 128 * i;
+        if (c < C) Quad<float>::load(gamma + c, gm[i]);
+        else gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sg[i][j] = sb[i][j] = 0.f;
+    }
+    for (int rb = wbase; rb < R; rb += stride) {
+        const bool valid = rb + half < R;
+        const int r = valid ? rb + half : R - 1;
+        const size_t base = (size_t)r * C;
+        const float mu = mean[r], rs = rstd[r];
+        float d[NQ][4], xh[NQ][4];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = 4 * hl + 128 * i;
+            if (c < C) {
+                Quad<T>::load(dh + base + c, d[i]);
+                Quad<T>::load(x + base + c, xh[i]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { d[i][j] = 0.f; xh[i][j] = mu; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xh[i][j] = (xh[i][j] - mu) * rs;
+                const float g = d[i][j] * gm[i][j];
+                a += g;
+                b += g * xh[i][j];
+            }
+        }
+        const float m1 = half_sum(a, lane) * invc, m2 = half_sum(b, lane) * invc;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int c = 4 * hl + 128 * i;
+            if (c < C) {
+                float o[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o[j] = rs * (d[i][j] * gm[i][j] - m1 - xh[i][j] * m2);
+                    if (valid) { sg[i][j] += d[i][j] * xh[i][j]; sb[i][j] += d[i][j]; }
+                }
+                if (valid) Quad<T>::store(dx + base + c, o);
+            }
+        }
+    }
+    // the block's eight half-waves meet in LDS: [slot][0..C) = dgamma part, [slot][512..512+C) = dbeta part
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const int c = 4 * hl + 128 * i;
+        if (c < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[i][j]; red[slot][512 + c + j] = sb[i][j]; }
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+        const int which = t / C, c = t - which * C;
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += red[k][which * 512 + c];
+        partial[((size_t)blockIdx.x * 2 + which) * C + c] = acc;
+    }
+}
+
+// Backward of residual_ln_fwd_kernel for one LayerNorm site.
 //   xhat = (x - mean) * rstd,  g = dh * gamma
 //   dx   = gin + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))          (grad wrt out_res)
 //   dy   = rowscale * dx  (T, optional)      acc += dx (fp32, optional: positional-embedding grad)
@@ -449,6 +579,43 @@ extern "C" int gm3d_residual_ln_bwd(const void* dh, const float* gin, const floa
     else
         hipLaunchKernelGGL(residual_ln_bwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, (const float*)dh, gin, x, mean,
                            rstd, gamma, rowscale, rows_per_sample, dx, (float*)dy, acc, partial, R);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_ln_plain_partial_rows(int R) { return R < 1 ? 0 : gm3d::ln_grid(R); }
+
+extern "C" int gm3d_ln_plain_fwd(const void* x, const float* gamma, const float* beta, float eps, void* h, float* mean, float* rstd,
+                                 int R, int C, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!x || !gamma || !beta || !h || !mean || !rstd || R < 0) return GM3D_EINVAL;
+    if (C < 4 || C % 4 || C > 512) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (R == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nq = (C + 127) / 128;
+#define GM3D_LNP_F(T_, NQ_) hipLaunchKernelGGL((ln_plain_fwd_kernel<T_, NQ_>), dim3(ln_fwd_grid(R)), dim3(256), 0, st, (const T_*)x, gamma, \
+                                               beta, eps, (T_*)h, mean, rstd, R, C)
+    if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_F(bf16_t, 1); else if (nq == 2) GM3D_LNP_F(bf16_t, 2); else if (nq == 3) GM3D_LNP_F(bf16_t, 3); else GM3D_LNP_F(bf16_t, 4); }
+    else { if (nq == 1) GM3D_LNP_F(float, 1); else if (nq == 2) GM3D_LNP_F(float, 2); else if (nq == 3) GM3D_LNP_F(float, 3); else GM3D_LNP_F(float, 4); }
+#undef GM3D_LNP_F
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_ln_plain_bwd(const void* dh, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
+                                 float* partial, int R, int C, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dh || !x || !mean || !rstd || !gamma || !dx || !partial || R < 1) return GM3D_EINVAL;
+    if (C < 4 || C % 4 || C > 512) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nq = (C + 127) / 128;
+#define GM3D_LNP_B(T_, NQ_) hipLaunchKernelGGL((ln_plain_bwd_kernel<T_, NQ_>), dim3(ln_grid(R)), dim3(256), 0, st, (const T_*)dh, (const T_*)x, \
+                                               mean, rstd, gamma, (T_*)dx, partial, R, C)
+    if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_B(bf16_t, 1); else if (nq == 2) GM3D_LNP_B(bf16_t, 2); else if (nq == 3) GM3D_LNP_B(bf16_t, 3); else GM3D_LNP_B(bf16_t, 4); }
+    else { if (nq == 1) GM3D_LNP_B(float, 1); else if (nq == 2) GM3D_LNP_B(float, 2); else if (nq == 3) GM3D_LNP_B(float, 3); else GM3D_LNP_B(float, 4); }
+#undef GM3D_LNP_B
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

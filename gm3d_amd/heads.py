@@ -57,6 +57,47 @@ class LinearBiasFn(torch.autograd.Function):
             return dx, dW, db, None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension (4 <= C <= 512, C % 4 == 0) on csrc/rowops.hip's plain LayerNorm: x in any float type
+    is normalised in `adt` storage with fp32 statistics -- one launch forward, one + one finish backward, no autocast casts, and the
+    gamma / beta gradients by our own deterministic column sums (hipGraph-replay-safe)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, eps, adt):
+        with torch.autocast("cuda", enabled=False):
+            C = x.shape[-1]
+            x2 = x.reshape(-1, C).to(adt).contiguous()
+            R = x2.shape[0]
+            h = torch.empty_like(x2)
+            mean = torch.empty(R, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+            wc, bc = _c32(w), _c32(b)
+            _launch("gm3d_ln_plain_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_ln_plain_fwd, _ptr(x2), _ptr(wc), _ptr(bc),
+                    float(eps), _ptr(h), _ptr(mean), _ptr(rstd), R, C, _DT[adt], _stream())
+            ctx.save_for_backward(x2, mean, rstd, w)
+            ctx.adt, ctx.shp, ctx.xdt = adt, x.shape, x.dtype
+            return h.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh):
+        with torch.autocast("cuda", enabled=False):
+            x2, mean, rstd, w = ctx.saved_tensors
+            adt = ctx.adt
+            R, C = x2.shape
+            dh2 = dh.reshape(R, C).to(adt).contiguous()
+            dx = torch.empty_like(x2)
+            nrows = lib.gm3d_ln_plain_partial_rows(R)
+            part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dh.device)
+            _launch("gm3d_ln_plain_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_ln_plain_bwd, _ptr(dh2), _ptr(x2), _ptr(mean),
+                    _ptr(rstd), _ptr(_c32(w)), _ptr(dx), _ptr(part), R, C, _DT[adt], _stream())
+            gb = _finish(part, nrows, 2 * C)
+            return dx.view(ctx.shp).to(ctx.xdt), gb[:C].to(w.dtype), gb[C:].to(w.dtype), None, None
+
+
+def layer_norm_supported(x, C):
+    return x.is_cuda and 4 <= C <= 512 and C % 4 == 0 and x.dtype in (torch.float32, torch.bfloat16)
+
+
 class PosEmbedFn(torch.autograd.Function):
     """center (B,G,3) f32 -> (B,G,384) adt.  The K=3 layer and its GELU are one streaming kernel; its backward is a
     pure reduction (xyz carries no gradient)."""

@@ -33,6 +33,7 @@ from .hierarchical_group import HierarchicalGroup
 
 
 FUSED_EMBED0 = True
+FUSED_LAYERNORM = True
 
 
 def radius_mask(center, radius):
@@ -73,6 +74,16 @@ def _linear(x, weight, bias=None):
 class Linear(nn.Linear):
     def forward(self, x):
         return _linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm on our own row kernel (heads.LayerNormFn) on the GPU: widths 96 / 192 / 384, output in the activation type."""
+
+    def forward(self, x):
+        from . import heads
+        if FUSED_LAYERNORM and self.elementwise_affine and heads.layer_norm_supported(x, x.shape[-1]):
+            return heads.LayerNormFn.apply(x, self.weight, self.bias, self.eps, heads._adt())
+        return super().forward(x)
 
 
 class Mlp(nn.Module):
@@ -138,10 +149,10 @@ class MaskedAttention(nn.Module):
 class MaskedBlock(nn.Module):
     def __init__(self, dim, num_heads, drop_path=0.0):
         super().__init__()
-        self.norm1 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
         self.attn = MaskedAttention(dim, num_heads)
         self.drop_path = M.DropPath(drop_path) if drop_path > 0.0 else nn.Identity()
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
         self.mlp = Mlp(dim, 4 * dim)
 
     def forward(self, x, bits=None):
@@ -216,7 +227,7 @@ class PointM2AE(nn.Module):
         for d, n in zip(dims, depths):
             self.encoder_blocks.append(BlockStack(d, n, self.num_heads, dpr[at:at + n]))
             at += n
-        self.encoder_norms = nn.ModuleList([nn.LayerNorm(d) for d in dims])
+        self.encoder_norms = nn.ModuleList([LayerNorm(d) for d in dims])
         ddims, ddepths = c["decoder_dims"], c["decoder_depths"]
         ddpr = [x.item() for x in torch.linspace(0, c["drop_path_rate"], sum(ddepths))]
         self.mask_token = nn.Parameter(torch.zeros(1, 1, ddims[0]))
@@ -225,7 +236,7 @@ class PointM2AE(nn.Module):
         self.h_decoder = nn.ModuleList([BlockStack(ddims[0], ddepths[0], self.num_heads, ddpr[:ddepths[0]]),
                                         BlockStack(ddims[1], ddepths[1], self.num_heads, ddpr[ddepths[0]:])])
         self.token_prop = nn.ModuleList([TokenPropagation(ddims[0] + ddims[1], [ddims[1] * 4, ddims[1]])])
-        self.decoder_norm = nn.LayerNorm(ddims[1])
+        self.decoder_norm = LayerNorm(ddims[1])
         self.rec_head = nn.Conv1d(ddims[1], 3 * c["group_sizes"][1], 1)
         self.loss_pred_head = nn.Sequential(nn.Conv1d(ddims[0], 1024, 1), nn.BatchNorm1d(1024), nn.LeakyReLU(negative_slope=0.2),
                                             nn.Conv1d(1024, ddims[0], 1))

@@ -130,6 +130,16 @@ int gm3d_patch_chamfer_loss_bwd(const void *pred, long long pred_bstride, const 
                                 long long ids_bstride, const int32_t *idx1, const int32_t *idx2, const float *gmean, int B, int T,
                                 int M, void *dpred, int dtype, gm3d_stream_t stream);
 
+/* Plain LayerNorm over (R, C) rows, 4 <= C <= 512, C % 4 == 0 (nn.LayerNorm of the 96 / 192 / 384-wide Point-M2AE levels):
+ * h = (x - mean) * rstd * gamma + beta in `dtype`, mean / rstd (R) f32 saved for the backward.  Backward: dx in `dtype`;
+ * partial (gm3d_ln_plain_partial_rows(R), 2, C) f32: [.][0] = per-block sums of dh * xhat (dgamma), [.][1] = of dh (dbeta), to be
+ * finished by gm3d_colsum_finish over 2*C columns. */
+int gm3d_ln_plain_partial_rows(int R);
+int gm3d_ln_plain_fwd(const void *x, const float *gamma, const float *beta, float eps, void *h, float *mean, float *rstd, int R,
+                      int C, int dtype, gm3d_stream_t stream);
+int gm3d_ln_plain_bwd(const void *dh, const void *x, const float *mean, const float *rstd, const float *gamma, void *dx,
+                      float *partial, int R, int C, int dtype, gm3d_stream_t stream);
+
 /* ---- Row-wise fused passes around the transformer-block GEMMs (gm3d_amd/csrc/rowops.hip) ------------
  * Together they restate timm-0.4.5 Block.forward (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146)
  * as driven by TransformerEncoder/Decoder.forward (models_mae_learn_loss.py:914-917,984-990).

@@ -125,3 +125,28 @@ def test_fused_stack_matches_per_op_modules(bf16, B, T, nblk, train):
     assert rel(res[True][1], res[False][1]) <= tol and rel(res[True][2], res[False][2]) <= tol
     for k in res[False][3]:
         assert rel(res[True][3][k], res[False][3][k]) <= tol, k
+
+
+@pytest.mark.parametrize("C", [96, 192, 384, 4, 512, 100])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("R", [1, 7, 4100])
+def test_plain_layernorm_any_width(R, C, dtype):
+    """gm3d_ln_plain_fwd/bwd (heads.LayerNormFn) against torch.nn.functional.layer_norm in fp64 on the same (rounded) inputs."""
+    from gm3d_amd import heads
+    g = torch.Generator().manual_seed(R * 1000 + C)
+    x = (torch.randn(R, C, generator=g) * 1.5 + 0.3).cuda().to(dtype).requires_grad_(True)
+    w = (torch.rand(C, generator=g) + 0.5).cuda().requires_grad_(True)
+    b = (torch.randn(C, generator=g) * 0.2).cuda().requires_grad_(True)
+    dy = torch.randn(R, C, generator=g).cuda().to(dtype)
+    assert heads.layer_norm_supported(x, C)
+    h = heads.LayerNormFn.apply(x, w, b, 1e-5, dtype)
+    h.backward(dy)
+    x64 = x.detach().double().requires_grad_(True)
+    w64, b64 = w.detach().double().requires_grad_(True), b.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(x64, (C,), w64, b64, 1e-5)
+    ref.backward(dy.double())
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+    assert float((h.double() - ref).abs().max()) <= tol * max(1.0, float(ref.abs().max()))
+    assert float((x.grad.double() - x64.grad).abs().max()) <= tol * max(1.0, float(x64.grad.abs().max()))
+    assert float((w.grad.double() - w64.grad).abs().max()) <= 2e-5 * max(1.0, float(w64.grad.abs().max()))
+    assert float((b.grad.double() - b64.grad).abs().max()) <= 2e-5 * max(1.0, float(b64.grad.abs().max()))
