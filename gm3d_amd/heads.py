@@ -223,6 +223,79 @@ class LossPredHeadFn(torch.autograd.Function):
             return dx, dW0, db0, s2, s1, dW1, db1, None, None, None, None
 
 
+class BnBcastActFn(torch.autograd.Function):
+    """a = act(BatchNorm1d(y0 + t[group])) on a (G*K, C) row layout: y0 (G*K, C) and the per-group term t (G, C) in `adt` (a
+    Conv1d bias in front of the BatchNorm is the constant case of t), act = ReLU / LeakyReLU(slope).  The streaming passes of the
+    mini-PointNet embed (csrc/embed.hip bn_bcast_*) as an autograd node of their own: batch statistics, running-statistic update,
+    normalise + activate forward; the two-pass BatchNorm backward with the gamma / beta sums by our own kernels.
+    meta: adt, training, eps, momentum, slope, K, grad."""
+
+    @staticmethod
+    def forward(ctx, y0, t, gamma, beta, rm, rv, nbt, meta):
+        with torch.autocast("cuda", enabled=False):
+            adt, training, K, slope = meta["adt"], meta["training"], meta["K"], meta["slope"]
+            G, C = t.shape
+            R = G * K
+            dev = y0.device
+            y0 = y0.reshape(R, C).to(adt).contiguous()
+            t = t.to(adt).contiguous()
+            st = None
+            if training:
+                nrows = lib.gm3d_embed_partial_rows(1, G, C)
+                part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
+                _launch("gm3d_bn_bcast_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0), _ptr(t),
+                        G, K, C, _ptr(part), _DT[adt], _stream())
+                st = _finish(part, nrows, 2 * C)
+            f32 = dict(dtype=torch.float32, device=dev)
+            scale, shift, mean, rstd = (torch.empty(C, **f32) for _ in range(4))
+            _launch("gm3d_bn_finalize", {"C": C}, lib.gm3d_bn_finalize, _ptr(st), float(R), _ptr(_c32(gamma)), _ptr(_c32(beta)),
+                    float(meta["eps"]), float(meta["momentum"]), _ptr(rm), _ptr(rv), _ptr(nbt), _ptr(scale), _ptr(shift), _ptr(mean),
+                    _ptr(rstd), C, int(training), _stream())
+            a = torch.empty(R, C, dtype=adt, device=dev)
+            _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu, _ptr(y0),
+                    _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
+            if meta["grad"] and any(ctx.needs_input_grad):
+                if not training:
+                    raise NotImplementedError("BnBcastActFn backward is implemented for train-mode BatchNorm only")
+                ctx.save_for_backward(y0, t, mean, rstd, scale, shift)
+                ctx.meta, ctx.dims = meta, (G, K, C)
+            return a
+
+    @staticmethod
+    def backward(ctx, da):
+        with torch.autocast("cuda", enabled=False):
+            y0, t, mean, rstd, scale, shift = ctx.saved_tensors
+            meta = ctx.meta
+            adt, slope = meta["adt"], meta["slope"]
+            G, K, C = ctx.dims
+            dev = da.device
+            da = da.reshape(G * K, C).to(adt).contiguous()
+            nrows = lib.gm3d_embed_partial_rows(1, G, C)
+            part = torch.empty(nrows, 2 * C, dtype=torch.float32, device=dev)
+            _launch("gm3d_bn_bcast_bwd_stats", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_stats, _ptr(da),
+                    _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), G, K, C, _ptr(part), float(slope), _DT[adt],
+                    _stream())
+            s12 = _finish(part, nrows, 2 * C)
+            s1, s2 = s12[:C], s12[C:]
+            dy = torch.empty(G * K, C, dtype=adt, device=dev)
+            dt = torch.empty(G, C, dtype=torch.float32, device=dev)
+            _launch("gm3d_bn_bcast_bwd_apply", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply, _ptr(da),
+                    _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2), _ptr(dy), _ptr(dt), G,
+                    K, C, float(slope), _DT[adt], _stream())
+            return dy, dt.to(adt), s2, s1, None, None, None, None
+
+
+def bn_bcast_act(y0, t, bn, K, slope=0.0):
+    """act(bn(y0 + t[group])) through BnBcastActFn for an nn.BatchNorm1d module `bn` (rows layout, K rows per group)."""
+    meta = {"adt": _adt(), "training": bn.training, "eps": bn.eps, "momentum": bn.momentum, "slope": slope, "K": K,
+            "grad": torch.is_grad_enabled()}
+    return BnBcastActFn.apply(y0, t, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked, meta)
+
+
+def bn_bcast_supported(x, C, K):
+    return x.is_cuda and C % 8 == 0 and 8 <= C <= 1024 and 1 <= K <= 255
+
+
 class ExpandRowsFn(torch.autograd.Function):
     """token (1,1,C) -> (B,N,C); backward = column sum over the B*N rows with our two-stage kernel."""
 

@@ -34,6 +34,7 @@ from .hierarchical_group import HierarchicalGroup
 
 FUSED_EMBED0 = True
 FUSED_LAYERNORM = True
+FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
 
 
 def radius_mask(center, radius):
@@ -101,6 +102,13 @@ class Mlp(nn.Module):
 
 def _lin(x, conv, bn=None, act=False):
     """Conv1d(k=1) (+ BatchNorm1d + ReLU) on a (rows, C) layout."""
+    if bn is not None and act and FUSED_EMBED_DEEP and x.is_cuda and x.shape[0] % 8 == 0:
+        from . import heads
+        C = conv.out_channels
+        if heads._adt() == torch.bfloat16 and heads.bn_bcast_supported(x, C, 8):
+            # Conv + BatchNorm + ReLU on the embed's streaming kernels: the conv bias is the (constant) per-group term
+            t = heads.ExpandRowsFn.apply(conv.bias.view(1, 1, -1), 1, x.shape[0] // 8, torch.bfloat16).reshape(-1, C)
+            return heads.bn_bcast_act(_linear(x, conv.weight, None), t, bn, 8)
     y = _linear(x, conv.weight, conv.bias)
     if bn is not None:
         y = bn(y)
@@ -119,8 +127,33 @@ class TokenEmbed(nn.Module):
         self.second_conv = nn.Sequential(nn.Conv1d(2 * b, mid, 1), nn.BatchNorm1d(mid), nn.ReLU(inplace=True), nn.Conv1d(mid, out_c, 1))
         self.out_c = out_c
 
+    def _forward_fused(self, groups):
+        """The same layers with the BatchNorms on the embed's streaming kernels (heads.BnBcastActFn) and the concatenation
+        [global | local] replaced by the two halves of the second conv's weight (local rows + a per-group term): no (rows, 2b)
+        tensor, no PyTorch BatchNorm over 262,144+ rows."""
+        from . import heads
+        B, G, k, C = groups.shape
+        adt = heads._adt()
+        c0, bn0, _, c1 = self.first_conv
+        c2, bn1, _, c3 = self.second_conv
+        x = groups.reshape(B * G * k, C)
+        t0 = heads.ExpandRowsFn.apply(c0.bias.view(1, 1, -1), 1, B * G, adt).reshape(B * G, -1)
+        a1 = heads.bn_bcast_act(_linear(x, c0.weight, None), t0, bn0, k)
+        f = _linear(a1, c1.weight, c1.bias)                                            # (rows, b)
+        b_ = f.shape[-1]
+        fg = f.view(B * G, k, b_).amax(dim=1)                                          # (B*G, b)
+        W3 = c2.weight.squeeze(-1)                                                     # (mid, 2b): [global | local] columns
+        a2 = heads.bn_bcast_act(_linear(f, W3[:, b_:], None), _linear(fg, W3[:, :b_], c2.bias), bn1, k)
+        z = _linear(a2, c3.weight, c3.bias)
+        return z.view(B * G, k, self.out_c).amax(dim=1).view(B, G, self.out_c)
+
     def forward(self, groups):
         B, G, k, C = groups.shape
+        if FUSED_EMBED_DEEP and groups.is_cuda and C != 3:
+            from . import heads
+            if heads._adt() == torch.bfloat16 and all(heads.bn_bcast_supported(groups, c, k) for c in
+                                                      (self.first_conv[0].out_channels, self.second_conv[0].out_channels)):
+                return self._forward_fused(groups)
         x = groups.reshape(B * G * k, C)
         f = _lin(_lin(x, self.first_conv[0], self.first_conv[1], True), self.first_conv[3])                  # (rows, b)
         fg = f.view(B * G, k, -1).amax(dim=1, keepdim=True).expand(-1, k, -1)

@@ -180,3 +180,49 @@ def test_embed_at_point_m2ae_level0_sizes(bf16):
             assert _err(g[k], ref_g[k]) <= 2 * _err(mg[k], ref_g[k]) + 1e-3 * float(ref_g[k].abs().max()) + 1e-6 * gnorm, k
         for k in ref_b:
             assert _err(b[k], ref_b[k]) <= 2 * _err(mb[k], ref_b[k]) + 1e-3 * float(ref_b[k].abs().max()) + 1e-6, k
+
+
+@pytest.mark.parametrize("in_c,out_c,G,k", [(96, 192, 256, 8), (192, 384, 64, 8)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_deep_token_embed_fused_vs_module(in_c, out_c, G, k, bf16):
+    """Point-M2AE's level-1 / level-2 token embeds (point_m2ae.TokenEmbed with token features as input) on heads.BnBcastActFn + split
+    second-conv weights (TokenEmbed._forward_fused) against the plain module: tokens, every parameter gradient, the input gradient
+    and the BatchNorm buffers.  fp32: as close to an fp64 CPU run as the fp32 op chain (x2); bf16: as close to fp32 as autocast (x2)."""
+    from gm3d_amd import point_m2ae as P
+    torch.manual_seed(in_c + G)
+    base = P.TokenEmbed(in_c, out_c).cuda().train()
+    with torch.no_grad():
+        for m in base.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.uniform_(0.5, 1.5); m.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(2, G, k, in_c, device="cuda") * 0.5
+    w = torch.randn(2, G, out_c, device="cuda")
+
+    def run(fused, amp):
+        enc = copy.deepcopy(base)
+        xi = x.clone().requires_grad_(True)
+        P.FUSED_EMBED_DEEP = False
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+            tok = enc._forward_fused(xi) if fused else enc(xi)
+            (tok.float() * w).sum().backward()
+        P.FUSED_EMBED_DEEP = True
+        g = {k_: p.grad.detach().double() for k_, p in enc.named_parameters()}
+        g["input"] = xi.grad.detach().double()
+        return tok.detach().double(), g, {k_: b.detach().double() for k_, b in enc.named_buffers()}
+
+    enc64 = copy.deepcopy(base).cpu().double()
+    x64 = x.cpu().double().requires_grad_(True)
+    tok64 = enc64(x64)
+    (tok64 * w.cpu().double()).sum().backward()
+    g64 = {k_: p.grad.detach().cuda() for k_, p in enc64.named_parameters()}
+    g64["input"] = x64.grad.cuda()
+    tok64 = tok64.detach().cuda()
+    gnorm = sum(float(v.pow(2).sum()) for v in g64.values()) ** 0.5
+    mtok, mg, mb = run(False, bf16)
+    tok, g, b = run(True, bf16)
+    tol_t, tol_g = (1e-5, 3e-5) if not bf16 else (2e-2, 1e-3)
+    assert _err(tok, tok64) <= 2 * _err(mtok, tok64) + tol_t * float(tok64.abs().max())
+    for k_ in g64:
+        assert _err(g[k_], g64[k_]) <= 2 * _err(mg[k_], g64[k_]) + tol_g * float(g64[k_].abs().max()) + 1e-6 * gnorm, k_
+    for k_ in mb:
+        assert _err(b[k_], mb[k_]) <= (1e-5 if not bf16 else 1e-2) * float(mb[k_].abs().max()) + 1e-6, k_
