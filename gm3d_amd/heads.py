@@ -237,6 +237,7 @@ class BnBcastActFn(torch.autograd.Function):
             G, C = t.shape
             R = G * K
             dev = y0.device
+            ctx.in_dtypes = (y0.dtype, t.dtype)
             y0 = y0.reshape(R, C).to(adt).contiguous()
             t = t.to(adt).contiguous()
             st = None
@@ -282,7 +283,7 @@ class BnBcastActFn(torch.autograd.Function):
             _launch("gm3d_bn_bcast_bwd_apply", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_bwd_apply, _ptr(da),
                     _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2), _ptr(dy), _ptr(dt), G,
                     K, C, float(slope), _DT[adt], _stream())
-            return dy, dt.to(adt), s2, s1, None, None, None, None
+            return dy.to(ctx.in_dtypes[0]), dt.to(ctx.in_dtypes[1]), s2, s1, None, None, None, None
 
 
 def bn_bcast_act(y0, t, bn, K, slope=0.0):
