@@ -34,7 +34,7 @@ SIGNATURES = {
     "gm3d_ln_plain_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_ln_plain_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_residual_ln_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
-    "gm3d_residual_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "gm3d_residual_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_ln_partial_rows": [_i],
     "gm3d_colsum_finish": [_vp, _i, _i, _i, _vp, _i, _vp],
     "gm3d_colsum_finish_batched": [_vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _i, _vp],

@@ -286,7 +286,8 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(const T* __restric
                                                               const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                               const float* __restrict__ rowscale, int rows_per_sample,
                                                               float* __restrict__ dx, T* __restrict__ dy,
-                                                              float* __restrict__ acc, float* __restrict__ partial, int R) {
+                                                              float* __restrict__ acc, T* __restrict__ acc_out,
+                                                              float* __restrict__ partial, int R) {
     __shared__ float red[3][8][LNC];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int slot = threadIdx.x >> 5;
@@ -344,6 +345,7 @@ __global__ __launch_bounds__(256) void residual_ln_bwd_kernel(const T* __restric
 #pragma unroll
                     for (int j = 0; j < 4; ++j) p4[j] += a[j];
                     Quad<float>::store(acc + base + c, p4);
+                    if (acc_out) Quad<T>::store(acc_out + base + c, p4);      // the finished sum in the GEMM-side type as well
                 }
                 if (dy) {
                     float y4[4];
@@ -564,21 +566,22 @@ extern "C" int gm3d_residual_ln_fwd(const float* res, const void* y, const float
 
 extern "C" int gm3d_residual_ln_bwd(const void* dh, const float* gin, const float* x, const float* mean,
                                     const float* rstd, const float* gamma, const float* rowscale, int rows_per_sample,
-                                    float* dx, void* dy, float* acc, float* partial, int R, int C, int dtype,
+                                    float* dx, void* dy, float* acc, void* acc_out, float* partial, int R, int C, int dtype,
                                     gm3d_stream_t stream) {
     using namespace gm3d;
     if (!dh || !x || !mean || !rstd || !gamma || !dx || !partial || R < 0) return GM3D_EINVAL;
     if (rowscale && rows_per_sample < 1) return GM3D_EINVAL;
+    if (acc_out && !acc) return GM3D_EINVAL;
     if (C != LNC) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (R == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GM3D_BF16)
         hipLaunchKernelGGL(residual_ln_bwd_kernel<bf16_t>, dim3(ln_grid(R)), dim3(256), 0, st, (const bf16_t*)dh, gin, x, mean,
-                           rstd, gamma, rowscale, rows_per_sample, dx, (bf16_t*)dy, acc, partial, R);
+                           rstd, gamma, rowscale, rows_per_sample, dx, (bf16_t*)dy, acc, (bf16_t*)acc_out, partial, R);
     else
         hipLaunchKernelGGL(residual_ln_bwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, (const float*)dh, gin, x, mean,
-                           rstd, gamma, rowscale, rows_per_sample, dx, (float*)dy, acc, partial, R);
+                           rstd, gamma, rowscale, rows_per_sample, dx, (float*)dy, acc, (float*)acc_out, partial, R);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -109,9 +109,11 @@ def residual_ln_fwd(res, y, bias, rowscale, rows_per_sample, add, gamma, beta, e
     return out_res, h, mean, rstd
 
 
-def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R, dy=None, partial=None):
+def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, acc, want_dy, adt, R, dy=None, partial=None,
+                    acc_out=None):
     """-> dx (R,C) f32, dy (R,C) adt | None, sums (3,C) f32 = [dgamma, dbeta, colsum(dy)].
-    With `partial` given (a (rows, 3C) slice of a batched buffer) the second stage is left to the caller."""
+    With `partial` given (a (rows, 3C) slice of a batched buffer) the second stage is left to the caller.
+    acc_out (R,C) adt: receives the updated `acc` in the activation type too."""
     dev = gamma.device
     dx = torch.empty(R, LNC, dtype=torch.float32, device=dev)
     if dy is None and want_dy:
@@ -122,7 +124,7 @@ def residual_ln_bwd(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, ac
         partial = torch.empty(nrows, 3 * LNC, dtype=torch.float32, device=dev)
     _launch("gm3d_residual_ln_bwd", {"R": R, "dtype": str(adt)}, lib.gm3d_residual_ln_bwd, _ptr(dh), _ptr(gin), _ptr(x),
             _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(rowscale), int(rows_per_sample), _ptr(dx), _ptr(dy), _ptr(acc),
-            _ptr(partial), R, LNC, _DT[adt], _stream())
+            _ptr(acc_out), _ptr(partial), R, LNC, _DT[adt], _stream())
     if defer:
         return dx, dy, None
     sums = torch.empty(3, LNC, dtype=torch.float32, device=dev)
@@ -300,6 +302,7 @@ class async_wgrad:
         return False
 
 
+DIRECT_INPUT_GRADS = True   # the stack backward writes dx / dpos in the activation type itself (no converting copies)
 FUSE_QKV_ATTENTION = True   # qkv GEMM + attention forward as one launch (bf16, 32 < T <= 64)
 PER_BLOCK = 11  # ln1.w ln1.b qkv.w proj.w proj.b ln2.w ln2.b fc1.w fc1.b fc2.w fc2.b
 
@@ -429,7 +432,7 @@ class TransformerStackFn(torch.autograd.Function):
                 saved += [u, m1, r1, qkv, lse, x1, m2, r2, f]
             res, y, bias, rs = x1, o, b2, dp2
         xf, hout, mf, rf = residual_ln_fwd(res, y, bias, rs, T, None, final_w, final_b, meta["final_eps"], adt, R,
-                                           want_res=need)
+                                           want_res=need, h=meta.get("hout"))
         if need:
             ctx.save_for_backward(final_w, xf, mf, rf, H1, A, H2, GG, *params, *saved)
         ctx.meta, ctx.shape, ctx.nblk = meta, (B, T, C), nblk
@@ -510,8 +513,17 @@ class TransformerStackFn(torch.autograd.Function):
             da = gemm.mm(d_p, WPT[i]) if fuse_mlp_bwd else d_p @ weight_cache.get(wproj, adt)
             dqkv = _attention_bwd(qkv, A[i], da, lse, B, T, H, scale, dqkv=DQ[i])
             dh1 = gemm.mm(dqkv, WQT[i]) if fuse_mlp_bwd else dqkv @ weight_cache.get(wqkv, adt)
-            G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
-                                        dy=DO[i - 1] if i > 0 else None, partial=PLN[2 * i])
+            last = DIRECT_INPUT_GRADS and i == 0 and nblk > 1 and adt != torch.float32 and ctx.in_dtypes == (adt, adt)
+            if last:
+                # the stack's input gradients in the inputs' own (activation) type, written by this last pass instead of two
+                # converting copies behind it: dy = 1 * dx (no DropPath factor in front of block 0), acc_out = the finished dpos
+                dx_a = torch.empty(R, C, dtype=adt, device=dev)
+                dpos_a = torch.empty(R, C, dtype=adt, device=dev)
+                G, _, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, None, T, dpos, True, adt, R, dy=dx_a, partial=PLN[0],
+                                          acc_out=dpos_a)
+            else:
+                G, d_o, _ = residual_ln_bwd(dh1, dx1, u, m1, r1, ln1w, dp2_prev, T, dpos, i > 0, adt, R,
+                                            dy=DO[i - 1] if i > 0 else None, partial=PLN[2 * i])
             if dpos is None:
                 dpos = G
             gi[0], gi[1] = SLN[2 * i, 0], SLN[2 * i, 1]
@@ -556,6 +568,8 @@ class TransformerStackFn(torch.autograd.Function):
         for i in range(nblk):
             grads[i * PER_BLOCK + 9], grads[i * PER_BLOCK + 7] = gw2[i], gw1[i]
             grads[i * PER_BLOCK + 3], grads[i * PER_BLOCK + 2] = gwp[i], gwq[i]
+        if last:
+            return (dx_a.view(B, T, C), dpos_a.view(B, T, C), None, g_final_w, g_final_b) + tuple(grads)
         dx = G.view(B, T, C).to(ctx.in_dtypes[0])
         return (dx, dpos.view(B, T, C).to(ctx.in_dtypes[1]), None, g_final_w, g_final_b) + tuple(grads)
 
@@ -594,9 +608,15 @@ def run_stack(blocks, final_norm, x, pos, training):
             x.record_stream(side)
             pos.record_stream(side)
         if LOCKSTEP:
-            # one launch of every chain in turn: the capture (and the graph executor's enqueue order) interleaves the branches
+            # one launch of every chain in turn: the capture (and the graph executor's enqueue order) interleaves the branches;
+            # every chain's final LayerNorm writes its rows of ONE output buffer (no concatenation afterwards)
+            T_, C_ = x.shape[1], x.shape[2]
+            out = torch.empty(B, T_, C_, dtype=adt, device=x.device)
+            for side in streams[1:]:
+                out.record_stream(side)
             with torch.autocast("cuda", enabled=False), torch.no_grad():
-                gens = [TransformerStackFn._forward_gen(_NoCtx(), x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h], meta, final_norm.weight,
+                gens = [TransformerStackFn._forward_gen(_NoCtx(), x[j * h:(j + 1) * h], pos[j * h:(j + 1) * h],
+                                                        dict(meta, hout=out[j * h:(j + 1) * h].view(h * T_, C_)), final_norm.weight,
                                                         final_norm.bias, *params) for j in range(ns)]
                 live = ns
                 while live:
@@ -618,7 +638,7 @@ def run_stack(blocks, final_norm, x, pos, training):
         for j in range(1, ns):
             main.wait_stream(streams[j])
             outs[j].record_stream(main)
-        return torch.cat(outs, dim=0)
+        return out if LOCKSTEP else torch.cat(outs, dim=0)
     return TransformerStackFn.apply(x, pos, meta, final_norm.weight, final_norm.bias, *params)
 
 

@@ -158,12 +158,12 @@ int gm3d_residual_ln_fwd(const float *res, const void *y, const float *bias, con
 
 /* Backward of one such site.  dh (R,C) `dtype` = grad of h; gin (R,C) f32 = grad already flowing on the
  * residual stream (NULL = none); x = the saved out_res.  Writes dx (R,C) f32 = grad wrt out_res,
- * dy (R,C) `dtype` = rowscale * dx (NULL to skip), acc (R,C) f32 += dx (NULL to skip; positional grad),
- * and per-workgroup column partial sums partial[gm3d_ln_partial_rows(R)][3][C] f32:
- * [0] dgamma, [1] dbeta, [2] colsum(dy) (= gradient of `bias`). */
+ * dy (R,C) `dtype` = rowscale * dx (NULL to skip), acc (R,C) f32 += dx (NULL to skip; positional grad), acc_out (R,C) `dtype` =
+ * the updated acc in the GEMM-side type as well (NULL to skip; needs acc), and per-workgroup column partial sums
+ * partial[gm3d_ln_partial_rows(R)][3][C] f32: [0] dgamma, [1] dbeta, [2] colsum(dy) (= gradient of `bias`). */
 int gm3d_residual_ln_bwd(const void *dh, const float *gin, const float *x, const float *mean,
                          const float *rstd, const float *gamma, const float *rowscale, int rows_per_sample,
-                         float *dx, void *dy, float *acc, float *partial, int R, int C, int dtype,
+                         float *dx, void *dy, float *acc, void *acc_out, float *partial, int R, int C, int dtype,
                          gm3d_stream_t stream);
 int gm3d_ln_partial_rows(int R);   /* rows of `partial` the call above writes */
 

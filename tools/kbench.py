@@ -63,7 +63,7 @@ for R in (3200, 8192):
         lambda: (r(R, C), r(R, C, dtype=torch.float32), r(R, C, dtype=torch.float32), torch.zeros(R, device=dev), torch.ones(R, device=dev),
                  torch.empty(R, C, device=dev), torch.empty(R, C, device=dev, dtype=bf), torch.empty(nrows, 3 * C, device=dev)),
         lambda dh, gin, x, mu, rs, dx, dy, part: check(lib.gm3d_residual_ln_bwd(_ptr(dh), _ptr(gin), _ptr(x), _ptr(mu), _ptr(rs), _ptr(g),
-                                                                                 _ptr(rsc), R // 128, _ptr(dx), _ptr(dy), None, _ptr(part),
+                                                                                 _ptr(rsc), R // 128, _ptr(dx), _ptr(dy), None, None, _ptr(part),
                                                                                  R, C, 1, _stream()), "ln_bwd"))
     C4 = 1536
     b4 = torch.zeros(C4, device=dev)
