@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/gm3d.h"
 
 #define GM3D_WAVE 64
@@ -13,6 +14,22 @@
     } while (0)
 
 namespace gm3d {
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of a kernel: one static instance per launch site
+// remembers, per device ordinal, how many bytes were granted (a process that launches on a second device, or two threads
+// racing through the first launch, set it again instead of skipping it).  hipGetDevice is thread-local and capture-safe.
+struct LdsAttr {
+    std::atomic<int> granted[32];
+    bool ensure(const void* fn, size_t lds) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return false;
+        const bool slot = dev >= 0 && dev < 32;
+        if (slot && granted[dev].load(std::memory_order_acquire) >= (int)lds) return true;
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+        if (slot) granted[dev].store((int)lds, std::memory_order_release);
+        return true;
+    }
+};
 
 // Squared distance with the evaluation order fixed by the oracle contract
 // ((dx*dx + dy*dy) + dz*dz, fp32, no FMA).  The translation unit is compiled with

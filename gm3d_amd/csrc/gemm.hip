@@ -336,13 +336,8 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
 #define GM3D_GEMM_LAUNCH_(KTT, WMI, LNA)                                                                                       \
     {                                                                                                                         \
-        static bool attr_done = false;                                                                                        \
-        if (!attr_done) {                                                                                                     \
-            if (hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel<KTT, WMI, LNA>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                                  \
-                return GM3D_ELAUNCH;                                                                                          \
-            attr_done = true;                                                                                                 \
-        }                                                                                                                     \
+        static LdsAttr attr;                                                                                            \
+        if (!attr.ensure((const void*)gemm_tn_bf16_kernel<KTT, WMI, LNA>, lds)) return GM3D_ELAUNCH;                    \
         hipLaunchKernelGGL((gemm_tn_bf16_kernel<KTT, WMI, LNA>), dim3(grid), dim3(256), lds, (hipStream_t)stream,             \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total,      \
                            (bf16_t*)G, ldg, (bf16_t*)P, ARG, ldp, bias_after_pool, (const bf16_t*)Fpre, ldfp, colpart,        \

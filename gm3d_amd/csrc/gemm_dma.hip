@@ -206,13 +206,8 @@ static int dma_launch(const void* A, const void* W, const float* bias, void* C, 
     const size_t lds = (size_t)2 * (bm + DBN) * 128;
 #define GM3D_DMA_LAUNCH(WMI, EPI)                                                                                        \
     {                                                                                                                    \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) {                                                                                                \
-            if (hipFuncSetAttribute((const void*)gemm_tn_dma_kernel<WMI, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                             \
-                return GM3D_ELAUNCH;                                                                                     \
-            attr_done = true;                                                                                            \
-        }                                                                                                                \
+        static LdsAttr attr;                                                                                            \
+        if (!attr.ensure((const void*)gemm_tn_dma_kernel<WMI, EPI>, lds)) return GM3D_ELAUNCH;                          \
         hipLaunchKernelGGL((gemm_tn_dma_kernel<WMI, EPI>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
                            (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg, \
                            (const bf16_t*)Fpre, ldfp, colpart);                                                          \

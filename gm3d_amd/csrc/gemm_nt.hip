@@ -176,12 +176,8 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
     if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int grid = (int)((total + 7) / 8 * 8);
     const size_t lds = (size_t)NT_NBUF * NT_STAGE;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GM3D_ELAUNCH;
-        attr_done = true;
-    }
+    static LdsAttr attr;
+    if (!attr.ensure((const void*)gemm_nt_bf16_kernel, lds)) return GM3D_ELAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dY, (const bf16_t*)X, out,
                        R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, N / 128, K / 128, (int)total);
     GM3D_CHECK_LAUNCH();

@@ -214,13 +214,8 @@ static int ring_launch(const void* A, const void* W, const float* bias, void* C,
     const size_t lds = (size_t)RNBUF * (bm + RBN) * 128;
 #define GM3D_RING_LAUNCH(WMI, RES)                                                                                        \
     {                                                                                                                    \
-        static bool attr_done = false;                                                                                   \
-        if (!attr_done) {                                                                                                \
-            if (hipFuncSetAttribute((const void*)gemm_tn_ring_kernel<WMI, RES>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                    (int)lds) != hipSuccess)                                                             \
-                return GM3D_ELAUNCH;                                                                                     \
-            attr_done = true;                                                                                            \
-        }                                                                                                                \
+        static LdsAttr attr;                                                                                            \
+        if (!attr.ensure((const void*)gemm_tn_ring_kernel<WMI, RES>, lds)) return GM3D_ELAUNCH;                         \
         hipLaunchKernelGGL((gemm_tn_ring_kernel<WMI, RES>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
                            (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, res, rowscale,    \
                            rows_per_sample, (const bf16_t*)add, U, stats, (bf16_t*)U16);                                 \

@@ -839,7 +839,9 @@ class SegmentedDDPStep:
 
 
 # --------------------------------------------------------------------------- the epoch loop
-_warm = {}      # id(model) -> eager iterations run so far (lazy initialisation, library workspaces, code objects)
+import weakref
+_warm = weakref.WeakKeyDictionary()   # model -> eager iterations run so far (lazy initialisation, library workspaces, code
+#                                       objects); weak keys: a new model at a recycled address starts from zero again
 EAGER_WARMUP_ITERS = 3
 
 
@@ -865,6 +867,12 @@ def run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, 
     Learning rate: per iteration, set only at the start of an accumulation window (P/:72-73)."""
     n_iter = len(data_loader)
     accum = getattr(args, "accum_iter", 1)
+    # P/engine_pretrain.py:62 `optimizer.zero_grad()` at the start of every epoch: micro-batches of a window the previous epoch
+    # left unfinished (len(data_loader) % accum_iter != 0) are discarded, not added to this epoch's first update
+    if getattr(optimizer, "GA", None) is not None:
+        optimizer.GA.zero_()
+    if optimizer is not None and accum > 1:
+        optimizer.zero_grad()
     sums, n_upd, gsum, lr = None, 0, None, 0.0
     bad = torch.zeros((), dtype=torch.bool, device=device)
     t0, seen = time.time(), 0
@@ -968,4 +976,4 @@ def train_one_epoch(model, data_loader, optimizer, device, epoch, loss_scaler=No
         return make_captured_step(model, model_ema, optimizer, args, example, epoch, grad_sync=grad_sync)
 
     return run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, log_writer=log_writer,
-                     print_freq=print_freq, model_key=id(model), use_graph=use_graph)
+                     print_freq=print_freq, model_key=model, use_graph=use_graph)

@@ -146,4 +146,4 @@ def train_one_epoch(model, classifier, data_loader, data_loader_classifier, crit
                                     fwd_bwd=step_forward_backward, extra={"model_teacher": model_teacher})
 
     return E.run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, log_writer=log_writer,
-                       print_freq=print_freq, loss_scale=loss_weights(epoch, args), model_key=id(model), use_graph=use_graph)
+                       print_freq=print_freq, loss_scale=loss_weights(epoch, args), model_key=model, use_graph=use_graph)

@@ -24,7 +24,8 @@ def fps(data, number):
 def extract_features(model, points, npoints=1024, bf16=False):
     """-> token features (B,64,384) of the eval-mode encoder (P/:427-433)."""
     raw = model.module if hasattr(model, "module") else model
-    pts = fps(points, npoints) if points.size(1) != npoints else fps(points, npoints)
+    pts = fps(points, npoints)      # the reference resamples unconditionally (P/main_pretrain_multi_gpu.py:430)
+    assert pts.size(1) == npoints
     mask = torch.zeros(pts.shape[0], raw.num_group, dtype=torch.bool, device=pts.device)
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=bf16):
         return raw(pts, mask, noaug=True, num_visible=raw.num_group).float()

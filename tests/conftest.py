@@ -34,6 +34,8 @@ def pytest_collection_finish(session):
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    # the invariant the docstring states, checked: nothing imported during collection may have touched the GPU
+    assert not torch.cuda.is_initialized(), "a test module initialised HIP at import: the DDP workers need a fresh parent"
     procs = []
     for rank in range(2):
         log = open(os.path.join(out, "rank%d.log" % rank), "w")

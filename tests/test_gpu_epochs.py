@@ -161,6 +161,53 @@ def test_accum_iter_two_equals_reference_loop_and_concatenated_batch():
     assert float((res["window"][1] - res["concat"][1]).abs().max() / res["concat"][1].abs().max()) <= 2e-2
 
 
+class _SnapshotLoader:
+    """Yields the batches; just before the last one it snapshots the model's buffers (stream-ordered clones)."""
+
+    def __init__(self, batches, model):
+        self.batches, self.model, self.snap = batches, model, None
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        for i, b in enumerate(self.batches):
+            if i == len(self.batches) - 1:
+                self.snap = [t.detach().clone() for t in self.model.buffers()]
+            yield b
+
+
+def test_partial_accumulation_window_is_discarded_at_the_epoch_boundary():
+    """len(data_loader) % accum_iter != 0: the reference calls optimizer.zero_grad() at the start of every epoch
+    (P/engine_pretrain.py:62), so the trailing micro-batch of epoch e never reaches an update.  Two runs from the same state --
+    a 3-iteration epoch followed by a 2-iteration epoch, differing ONLY in the stray third batch -- must end with identical
+    parameters: the stray batch's other trace, the student's BatchNorm running statistics, is rolled back to what it was before
+    that batch, so only a leak of its gradient into the next epoch's first window could tell the runs apart (the flat
+    optimizer's GA buffer used to carry it).  Eager and hipGraph replay."""
+    from gm3d_amd import engine_pretrain as E
+    B = 4
+    data = [clouds.gaussian(B, 1024, seed=90 + i).cuda() for i in range(6)]
+    for use_graph in (False, True):
+        ends = []
+        for stray in (2, 5):
+            E_, model, ema, opt, args = _pretrain_setup(B, accum=2, drop_path=False)
+            torch.manual_seed(5)            # mask noise / augmentation draws: same sequence in both runs
+            E._warm.clear()
+            loader = _SnapshotLoader([data[0], data[1], data[stray]], model)
+            E_.train_one_epoch(model, loader, opt, torch.device("cuda"), 10, None, args=args, model_ema=ema, use_graph=False)
+            with torch.no_grad():
+                for t, v in zip(model.buffers(), loader.snap):
+                    t.copy_(v)
+            torch.manual_seed(6)
+            if use_graph:
+                E._warm[model] = 10 * E.EAGER_WARMUP_ITERS      # capture before the first iteration of the second epoch
+            s = E_.train_one_epoch(model, Loader([data[3], data[4]]), opt, torch.device("cuda"), 11, None, args=args,
+                                   model_ema=ema, use_graph=use_graph)
+            assert s["replayed_iters"] == (2 if use_graph else 0)
+            ends.append(opt.P.clone())
+        assert torch.equal(ends[0], ends[1]), (use_graph, float((ends[0] - ends[1]).abs().max()))
+
+
 def test_finetune_train_one_epoch_and_evaluate():
     from gm3d_amd import engine_finetune as EF
     from gm3d_amd.point_transformer import PointTransformer

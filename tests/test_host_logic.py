@@ -143,3 +143,19 @@ def test_shard_for_rank():
     assert all(len(p) == 26 for p in parts)
     assert set(torch.cat(parts).tolist()) == set(range(103))
     assert not torch.equal(shard_for_rank(103, 0, 4, epoch=4, seed=1), parts[0])      # set_epoch reshuffles
+
+
+def test_collection_from_the_repo_root_needs_no_gpu():
+    """`python -m pytest --collect-only` from the repo ROOT (no `tests` argument) must succeed on a machine without a GPU:
+    pytest.ini restricts collection to tests/ (a diagnostic under tools/ once matched *_test.py and made HIP calls at import,
+    which also broke the fresh-parent invariant of tests/conftest.py::pytest_collection_finish on the GPU box), and no test
+    module may touch the GPU at import (conftest asserts that before it starts the data-parallel workers)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")      # a GPU box looks like a CPU box to the child
+    r = subprocess.run([sys.executable, "-m", "pytest", "--collect-only", "-q", "-p", "no:cacheprovider"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "tools/" not in r.stdout and "error" not in r.stdout.lower().split("\n")[-2]

@@ -1,5 +1,5 @@
 """Are memcpy / memset NODES of a captured hipGraph replay-safe on this stack when the process makes other copies after the capture?
-(The memset case is not: tools/m2ae_graph_diag.py)   python tools/graph_memcpy_test.py"""
+(The memset case is not: tools/m2ae_graph_diag.py)   python tools/graph_memcpy_diag.py"""
 import torch
 
 dev = "cuda"
