@@ -48,6 +48,29 @@ def test_fps_large_cloud(gops, oracle_ops):
     assert torch.equal(gops.furthest_point_sample(dev(x), 64).cpu(), ref)
 
 
+def test_fps_matches_reference_numpy_fps(gops):
+    """gm3d_fps against the ONE statement of FPS the reference tree holds (P/datasets/ModelNetDataset.py:25-46, run in place by
+    tests/golden/make_golden_fps.py: start rotated to index 0, clouds clear of the 1e-3 ball).  No oracle involved: the
+    fixture holds the reference's own output.  Cases: 1024->64 (pretrain grouping), 8192->1024 (SVM validation), 8192->1200
+    (fine-tune), and the `_tight` ones, which only the reference's float32 arithmetic reproduces (its float64 run differs)."""
+    import os
+    import numpy as np
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "fps_modelnet.npz"))
+    names = sorted({k.split("/")[0] for k in fx.files})
+    assert len(names) >= 5
+    for n in names:
+        xyz, want, pts = torch.from_numpy(fx[n + "/xyz"]), torch.from_numpy(fx[n + "/idx"]), torch.from_numpy(fx[n + "/points"])
+        idx, cen = gops.fps(dev(xyz[None]), len(want))
+        assert torch.equal(idx.cpu()[0], want), n
+        assert torch.equal(cen.cpu()[0], pts), n
+    # all cases of one size as ONE batch (the kernel's per-cloud workgroups must not interact)
+    big = [n for n in names if fx[n + "/xyz"].shape[0] == 8192]
+    x = torch.stack([torch.from_numpy(fx[n + "/xyz"]) for n in big])
+    idx, _ = gops.fps(dev(x), 1024)
+    for i, n in enumerate(big):
+        assert torch.equal(idx.cpu()[i], torch.from_numpy(fx[n + "/idx"][:1024])), n      # FPS is prefix-stable
+
+
 @pytest.mark.parametrize("family", ["uniform", "gaussian", "lattice", "duplicates"])
 @pytest.mark.parametrize("N,G,k", [(1024, 64, 32), (1024, 128, 16), (1024, 256, 8), (100, 7, 64), (2048, 33, 5),
                                    (1000, 10, 1), (777, 5, 32), (64, 3, 64)])

@@ -95,3 +95,24 @@ def test_lr_schedule():
     fx = np.load(os.path.join(GOLD, "lr_sched.npz"))
     got = [R.adjust_learning_rate(float(e), 1e-3, 0.0, 40, 400) for e in fx["epochs"]]
     assert np.allclose(got, fx["lrs"], rtol=1e-12, atol=0)
+
+
+# ---- FPS against the reference's own NumPy statement (tests/golden/make_golden_fps.py; P/datasets/ModelNetDataset.py:25-46) ----
+def _fps_cases():
+    import os
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "fps_modelnet.npz"))
+    names = sorted({k.split("/")[0] for k in fx.files})
+    return fx, names
+
+
+def test_oracle_fps_matches_reference_numpy_fps(oracle_ops):
+    """oracle_fps (start 0, skip rule vacuous on these clouds, fp32 (dx*dx+dy*dy)+dz*dz, first maximum) selects exactly the
+    points the reference's farthest_point_sample returned -- including the `_tight` cases, where the reference's float64 run
+    differs from its float32 run, i.e. only the fp32 rounding contract reproduces the selection."""
+    fx, names = _fps_cases()
+    assert len(names) >= 5
+    for n in names:
+        xyz, idx, pts = fx[n + "/xyz"], fx[n + "/idx"], fx[n + "/points"]
+        got = oracle_ops.furthest_point_sample(torch.from_numpy(xyz)[None], len(idx)).numpy()[0]
+        assert np.array_equal(got, idx), n
+        assert np.array_equal(xyz[got], pts), n
