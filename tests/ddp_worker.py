@@ -48,18 +48,17 @@ def run(rank, world, port, out, B=4, steps=3):
         seg = E.SegmentedDDPStep(m, ema, opt, args, data[0][ids].cuda(), 200, warmup_iters=0, augment=False,
                                  inject_mask_noise=True, use_graphs=(mode == "graph"))
         p_start = opt.P.clone()
-        # this rank's shard alone: the three segments without their collectives -- through the SAME executor as the step (the
-        # captured graphs in graph mode: an eager re-run may pick another library GEMM solution, i.e. other bf16 roundings)
+        # this rank's shard alone: the three segments without their collectives, run EAGERLY in both modes -- the captured
+        # step of graph mode is compared with eager execution, not with itself
         seg.static_noise.copy_(noise[0][ids].cuda())
-        if mode == "graph":
-            seg.static_in.copy_(data[0][ids].cuda())
-            for k in range(3):
-                seg.graphs[k].replay()
-        else:
-            seg._phase1(data[0][ids].cuda())
-            seg._phase2()
-            seg._phase3()
-            seg._cut1 = seg._cut2 = seg._cut3 = None
+        bufs = [t.detach().clone() for t in m.buffers()]
+        seg._phase1(data[0][ids].cuda())
+        seg._phase2()
+        seg._phase3()
+        seg._cut1 = seg._cut2 = seg._cut3 = None
+        with torch.no_grad():                               # the extra forward moved the BatchNorm running statistics: roll back
+            for t, v in zip(m.buffers(), bufs):
+                t.copy_(v)
         torch.cuda.synchronize()
         g_local = opt.G.clone()
         losses, g_avg = [], None

@@ -76,11 +76,11 @@ def test_b128_bf16_graph_replay_equals_eager_and_fp32_band():
         torch.cuda.synchronize()
         got.append([float(o[k]) for k in keys])
         assert torch.equal(o["mask"], masks[i])                 # same teacher, same noise: identical masks
-    for a, b in zip(got, eager[3:]):
-        for x, y in zip(a, b):
-            assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, eager[3:])
-    worst = float((opt.P - p_eager).abs().max() / p_eager.abs().max())
-    assert worst <= 2e-2, worst
+    # replay == eager, EXACTLY: every kernel of the step is deterministic (own kernels with fixed-order reductions; the index
+    # gathers' backward scatters over permutations, i.e. without colliding atomics) and a captured launch runs the same code on
+    # the same operands (tools/eager_vs_graph_diag.py: flat gradient buffer bit-identical eager vs captured, B = 4 and 32)
+    assert got == eager[3:], (got, eager[3:])
+    assert torch.equal(opt.P, p_eager), float((opt.P - p_eager).abs().max())
     del g, m, ema, opt
 
     # fp32 eager step on the first batch: the bf16 losses of step 0 within the bf16 band (8 mantissa bits through 16 blocks)

@@ -37,17 +37,18 @@ def test_two_rank_segmented_step_real_model(ddp_results, mode):
     # (2) averaged gradient: identical on both ranks, and the mean of the two local ones
     assert torch.equal(r0["g_avg"], r1["g_avg"])
     assert not torch.equal(r0["g_local"], r1["g_local"])
-    want = (r0["g_local"] + r1["g_local"]) * 0.5
+    # g_local is ALWAYS computed eagerly (also in graph mode: tests/ddp_worker.py), g_avg by the step under test.  The step's
+    # kernels are deterministic and a captured launch runs the same code on the same operands, gloo sums the two ranks' buffers
+    # (one rounding) and the step halves the sum (exact): the averaged gradient EQUALS (g0 + g1) / 2 computed here.
+    want = (r0["g_local"] + r1["g_local"]) / 2
     for seg, (lo, hi) in r0["segments"].items():
         a, b = r0["g_avg"][lo:hi], want[lo:hi]
-        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
-        if err > 2e-3:      # name the parameters (diagnosis of a failure)
+        if not torch.equal(a, b):      # name the parameters (diagnosis of a failure)
             offs = r0["offs"] + [r0["g_avg"].numel()]
             worst = sorted(((float((r0["g_avg"][o:e] - want[o:e]).abs().max()) / float(b.abs().max()), n)
                             for n, o, e in zip(r0["names"], offs[:-1], offs[1:]) if lo <= o < hi), reverse=True)[:6]
             loc = [float((r["g_avg"][lo:hi] - r["g_local"][lo:hi]).abs().max()) for r in (r0, r1)]
-            raise AssertionError((mode, seg, err, worst, loc))
-        # same kernels on the same inputs; only atomic scatter-adds reorder sums
+            raise AssertionError((mode, seg, worst, loc))
     # (3) replicas stay bit-identical
     assert torch.equal(r0["params"], r1["params"]) and not torch.equal(r0["params"], r0["p_start"])
     assert torch.equal(r0["ema"], r1["ema"])
@@ -62,11 +63,9 @@ def test_two_rank_segmented_step_real_model(ddp_results, mode):
 def test_two_rank_graph_equals_eager(ddp_results):
     e0, _ = _load(ddp_results, "eager")
     g0, _ = _load(ddp_results, "graph")
-    for a, b in zip(e0["losses"], g0["losses"]):
-        for x, y in zip(a, b):
-            assert abs(x - y) <= 2e-2 * abs(y), (e0["losses"], g0["losses"])
-    worst = float((e0["params"] - g0["params"]).abs().max())
-    assert worst <= 2e-2 * float(e0["params"].abs().max()), worst
+    assert e0["losses"] == g0["losses"], (e0["losses"], g0["losses"])          # exact, step by step
+    assert torch.equal(e0["params"], g0["params"]) and torch.equal(e0["ema"], g0["ema"])
+    assert torch.equal(e0["g_avg"], g0["g_avg"])
 
 
 def test_two_rank_train_one_epoch(ddp_results):

@@ -54,10 +54,10 @@ def test_graph_replay_equals_eager(bf16):
         o = g(pool[i % 3], noise[i])
         torch.cuda.synchronize()
         got.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
-    tol = 2e-2 if bf16 else 2e-4       # identical kernels; only the atomic scatter-adds of gather's backward reorder sums
-    for a, b in zip(got, eager[3:]):
-        for x, y in zip(a, b):
-            assert x == x and abs(x - y) <= tol * abs(y), (got, eager[3:])
+    # identical kernels on identical operands, every reduction in a fixed order (the index gathers scatter over permutations:
+    # their backward atomics never collide) -> the trajectories are EQUAL, not close (tools/eager_vs_graph_diag.py)
+    assert all(x == x for a in got for x in a)
+    assert got == eager[3:], (got, eager[3:])
 
 
 def test_two_graph_data_parallel_path_on_one_gpu():
@@ -107,9 +107,8 @@ def test_two_graph_data_parallel_path_on_one_gpu():
                 torch.cuda.synchronize()
                 hist.append([float(o["loss_chfr"]), float(o["grad_norm"])])
         res[mode] = hist
-    for a, b in zip(res["graph"], res["eager"]):
-        for x, y in zip(a, b):
-            assert x == x and abs(x - y) <= 2e-2 * abs(y), res
+    assert all(x == x for a in res["graph"] for x in a)
+    assert res["graph"] == res["eager"], res           # exact: same kernels, fixed-order reductions
 
 
 @pytest.mark.parametrize("use_graphs", [False, True])
@@ -165,12 +164,19 @@ def test_segmented_ddp_step_equals_single_backward(use_graphs):
         o = seg(pool[i % 3].clone(), noise[i])
         torch.cuda.synchronize()
         got.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+    # Every gradient is produced by the same kernel on the same operands in both layouts (a cut tensor's gradient is one tensor
+    # either way, never a sum over segments): the losses of the first step are EQUAL.  The segment-ordered flat layout changes the
+    # order in which the clip's norm sums the buffer, so the norm may differ in its last bits, with it the clip factor (the norm
+    # is ~10 here, above max_norm = 5), then parameters by ~1e-7 relative, a few bf16 weight shadows by one ulp, and the later
+    # steps' losses at the 1e-4 level: stated bounds 1e-6 (norm, step 0), 1e-3 (later steps), 1e-4 (parameters).
+    assert got[0][0] == ref[0][0] and got[0][1] == ref[0][1], (got[0], ref[0])
+    assert abs(got[0][2] - ref[0][2]) <= 1e-6 * abs(ref[0][2]), (got[0], ref[0])
     for a, b in zip(got, ref):
         for x, y in zip(a, b):
-            assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, ref)
+            assert x == x and abs(x - y) <= 1e-3 * abs(y), (got, ref)
     worst = max(float((p.detach().float() - ref_params[k].float()).abs().max() / ref_params[k].float().abs().max().clamp_min(1e-3))
                 for k, p in m2.named_parameters())
-    assert worst <= 2e-2, worst
+    assert worst <= 1e-4, worst
 
 
 def test_segmented_ddp_step_through_rccl_group_of_one():
@@ -211,9 +217,8 @@ def test_segmented_ddp_step_through_rccl_group_of_one():
         got = run()
     finally:
         dist.destroy_process_group()
-    for a, b in zip(got, ref):
-        for x, y in zip(a, b):
-            assert x == x and abs(x - y) <= 2e-2 * abs(y), (got, ref)
+    assert all(x == x for a in got for x in a)
+    assert got == ref, (got, ref)                      # a one-rank mean all-reduce is the identity: exact
 
 
 def test_parallel_decoders_equal_serial():
