@@ -96,6 +96,8 @@ SIGNATURES = {
     "gm3d_pn_layer1_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_colsum_finish_f64": [_vp, _i, _i, _i, _vp, _vp],
     "gm3d_colsum_partial": [_vp, _i, _i, _vp, _i, _vp],
+    "gm3d_colsum_partial_w": [_vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_gemm_tn_bf16_dmaw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 
 

@@ -406,9 +406,12 @@ __global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __
     }
 }
 
-// Generic column partial sums of a (R,C) matrix: partial[block][c]
+// Generic column partial sums of a (R,C) matrix: partial[block][c]; with `roww` (R) the rows are weighted: sum_r roww[r] m[r][c]
+// (the loss-prediction head's  a^T d  -- the gradient of its folded output vector -- as a deterministic two-stage sum instead of a
+// library GEMV)
 template <class T>
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ m, int R, int C, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ m, int R, int C, float* __restrict__ partial,
+                                                             const float* __restrict__ roww) {
     extern __shared__ float sm[];
     const int tpr = C >> 3, SL = blockDim.x / tpr;
     const int lane = threadIdx.x % tpr, sl = threadIdx.x / tpr, c = lane * 8;
@@ -418,8 +421,9 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict
     for (size_t r = (size_t)blockIdx.x * SL + sl; r < (size_t)R; r += (size_t)gridDim.x * SL) {
         float v[8];
         V8<T>::load(m + r * C + c, v);
+        const float wr = roww ? roww[r] : 1.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[0][i] += v[i];
+        for (int i = 0; i < 8; ++i) acc[0][i] += wr * v[i];
     }
     write_partials<1>(acc, sm, partial, C, c, sl, SL);
 }
@@ -1146,7 +1150,12 @@ extern "C" int gm3d_colsum_finish_f64(const double* partial, int nrows, int pitc
     return GM3D_OK;
 }
 
+extern "C" int gm3d_colsum_partial_w(const void* m, const float* roww, int R, int C, float* partial, int dtype, gm3d_stream_t stream);
 extern "C" int gm3d_colsum_partial(const void* m, int R, int C, float* partial, int dtype, gm3d_stream_t stream) {
+    return gm3d_colsum_partial_w(m, nullptr, R, C, partial, dtype, stream);
+}
+
+extern "C" int gm3d_colsum_partial_w(const void* m, const float* roww, int R, int C, float* partial, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!m || !partial || R < 1) return GM3D_EINVAL;
     if (C < 8 || C % 8 || C > 2048) return GM3D_EUNSUPPORTED;          // one thread per 8 columns, at most 256 threads per row slice
@@ -1155,9 +1164,9 @@ extern "C" int gm3d_colsum_partial(const void* m, int R, int C, float* partial, 
     hipStream_t st = (hipStream_t)stream;
     GM3D_DISPATCH(dtype,
                   hipLaunchKernelGGL(colsum_partial_kernel<bf16_t>, dim3(row_grid(R, C)), dim3(threads_for(C)), lds, st,
-                                     (const bf16_t*)m, R, C, partial),
+                                     (const bf16_t*)m, R, C, partial, roww),
                   hipLaunchKernelGGL(colsum_partial_kernel<float>, dim3(row_grid(R, C)), dim3(threads_for(C)), lds, st,
-                                     (const float*)m, R, C, partial));
+                                     (const float*)m, R, C, partial, roww));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -13,6 +13,11 @@
 // one multiplies, the other's loads and epilogue stores run.  Measured inside the fused qkv + attention kernel
 // (csrc/attention.hip) this shape ran the 4096 x 1152 x 384 product in about 6.5 us against 11.3 (library) / 12.4 (gemm.hip).
 // Accumulation order is that of gemm.hip / gemm_ring.hip (k ascending in steps of 16 inside 32x32x16 MFMAs): identical bits.
+//
+// Round 3: the tile WIDTH is a template parameter (NJ 32-column MFMA tiles per wave: 128 / 192 / 256 columns).  The 256-wide form
+// serves the mini-PointNet convolutions over the 262,144 point rows (Encoder.second_conv, P/models_mae_learn_loss.py:878-883, and
+// their input gradients: N = 512 / 256), which are HBM-bound products (A read once + C written once = 400 MB at N = 512): a
+// 128 x 256 tile moves 1 byte from L2 per 85 flops (128 x 128: 64), so the L2 -> CU stream stays below the HBM stream.
 #include "common.hpp"
 
 namespace gm3d {
@@ -21,7 +26,7 @@ typedef __bf16 dbf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 dbf16x4 __attribute__((ext_vector_type(4)));
 typedef float df32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int DBN = 192, DBK = 64;
+constexpr int DBK = 64;
 
 __device__ __forceinline__ int dma_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
 __device__ __forceinline__ int dma_off(int row, int ch) { return row * 128 + ((ch ^ dma_f(row)) << 4); }
@@ -40,16 +45,16 @@ __device__ __forceinline__ void dma_glds16(const void* gsrc, unsigned dst) {
 //               G = GELU(bf16(A.W^T) + bias)                                   (as gm3d_gemm_tn_bf16_gelu)
 //      2  fc2 input gradient: C = bf16(A.W^T) * GELU'(Fpre + bias), colpart[tile_m][n] = the tile's column sums of the fp32
 //               products (the fc1 bias gradient, finished later)                  (as gm3d_gemm_tn_bf16_gelu_bwd)
-template <int WMI, int EPI>
+template <int WMI, int EPI, int NJ>
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
                                                              int lda, int ldw, int ldc, int tiles_n, int total_tiles,
                                                              bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ Fpre,
                                                              int ldfp, float* __restrict__ colpart) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
-    constexpr int BM = 64 * WMI;
+    constexpr int BM = 64 * WMI, DBN = 64 * NJ;
     constexpr int STAGE = (BM + DBN) * 128;                 // bytes
-    constexpr int PA = BM / 8, PIECES = (PA + 24) / 4;      // 1-KiB pieces of the A tile; pieces per wave per stage (8 or 10)
+    constexpr int PA = BM / 8, PIECES = (PA + DBN / 8) / 4; // 1-KiB pieces of the A tile; pieces per wave per stage (6 .. 12)
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int per_xcd = gridDim.x >> 3;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
     if (logical >= total_tiles) return;
     const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * DBN;
-    const int wm = (w >> 1) * 32 * WMI, wn = (w & 1) * 96;
+    const int wm = (w >> 1) * 32 * WMI, wn = (w & 1) * 32 * NJ;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)dsm;
 
     const int prow = lane >> 3, pslot = lane & 7;
@@ -80,11 +85,11 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
         _Pragma("unroll") for (int i = 0; i < PIECES; ++i)                                          \
             dma_glds16(src[i] + (size_t)(ST) * DBK, base + 1024 * (w + 4 * i));                     \
     }
-    df32x16 acc[WMI][3];
+    df32x16 acc[WMI][NJ];
 #pragma unroll
     for (int i = 0; i < WMI; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 #pragma unroll
             for (int i = 0; i < WMI; ++i) fa[i] = *reinterpret_cast<const dbf16x8*>(as + dma_off(wm + 32 * i + r, 2 * s + hh));
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+            for (int j = 0; j < NJ; ++j) {
                 const dbf16x8 fw = *reinterpret_cast<const dbf16x8*>(ws + dma_off(wn + 32 * j + r, 2 * s + hh));
 #pragma unroll
                 for (int i = 0; i < WMI; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw, fa[i], acc[i][j], 0, 0, 0);
@@ -111,12 +116,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
     }
 #undef GM3D_DMA_STAGE
     __syncthreads();                 // every wave is done with the stages: they become the bf16 staging images of the epilogue
-    // acc[i][j][g]: row wm + 32 i + r, column wn + 32 j + crow(g) (4 consecutive per quad: 8 q + 4 hh + e).  Staged as three
+    // acc[i][j][g]: row wm + 32 i + r, column wn + 32 j + crow(g) (4 consecutive per quad: 8 q + 4 hh + e).  Staged as NJ
     // [BM][64] bf16 images (swizzled 128-byte rows, the layout of the stages), read back as whole 16-byte chunks of a row.
 #pragma unroll
     for (int i = 0; i < WMI; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int row = wm + 32 * i + r, col = wn + 32 * j;
             unsigned char* img = dsm + (col >> 6) * (BM * 128);
             const int cbase = (col & 63) >> 3;
@@ -135,13 +140,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
         }
     __syncthreads();
     // thread -> chunk ch = tid & 7 of rows (tid >> 3) + 32 k of image t: i = 2 WMI t + k
-    float csum[3][8];
+    float csum[NJ][8];
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < NJ; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) csum[t][e] = 0.f;
 #pragma unroll
-    for (int i = 0; i < 6 * WMI; ++i) {                          // 3 images x BM rows x 8 chunks = 6 WMI x 256 threads
+    for (int i = 0; i < 2 * NJ * WMI; ++i) {                     // NJ images x BM rows x 8 chunks = 2 NJ WMI x 256 threads
         const int c = tid + 256 * i;
         const int t = i / (2 * WMI), row = (c - t * (BM * 8)) >> 3, ch = tid & 7;
         if (m0 + row < M) {
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
         __syncthreads();
         float* cs = reinterpret_cast<float*>(dsm);
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < NJ; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) cs[(tid >> 3) * DBN + 64 * t + 8 * (tid & 7) + e] = csum[t][e];
         __syncthreads();
@@ -191,33 +196,40 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 }  // namespace gm3d
 
 static int dma_launch(const void* A, const void* W, const float* bias, void* C, void* G, int M, int N, int K, int lda, int ldw, int ldc,
-                      int ldg, int bm, gm3d_stream_t stream, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr) {
+                      int ldg, int bm, gm3d_stream_t stream, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr,
+                      int bn = 192) {
     using namespace gm3d;
     if (!A || !W || (!C && !G) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if ((G || Fpre) && !bias) return GM3D_EINVAL;
     if (Fpre && (!C || !colpart || G || ldfp % 8 || ldfp < N || ((size_t)Fpre & 15))) return GM3D_EINVAL;
-    if (N % DBN || K % DBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N)))
+    if (bn != 128 && bn != 192 && bn != 256) return GM3D_EUNSUPPORTED;
+    if ((G || Fpre) && bn != 192) return GM3D_EUNSUPPORTED;          // the GELU epilogues exist for the 192-column tile only
+    if (N % bn || K % DBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N)))
         return GM3D_EUNSUPPORTED;
     if ((((size_t)A | (size_t)W | (size_t)C | (size_t)G) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / DBN;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / bn;
     if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
-    const size_t lds = (size_t)2 * (bm + DBN) * 128;
-#define GM3D_DMA_LAUNCH(WMI, EPI)                                                                                        \
+    const size_t lds = (size_t)2 * (bm + bn) * 128;
+#define GM3D_DMA_LAUNCH(WMI, EPI, NJ)                                                                                    \
     {                                                                                                                    \
-        static LdsAttr attr;                                                                                            \
-        if (!attr.ensure((const void*)gemm_tn_dma_kernel<WMI, EPI>, lds)) return GM3D_ELAUNCH;                          \
-        hipLaunchKernelGGL((gemm_tn_dma_kernel<WMI, EPI>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, (bf16_t*)G, ldg, \
-                           (const bf16_t*)Fpre, ldfp, colpart);                                                          \
+        static LdsAttr attr;                                                                                             \
+        if (!attr.ensure((const void*)gemm_tn_dma_kernel<WMI, EPI, NJ>, lds)) return GM3D_ELAUNCH;                       \
+        hipLaunchKernelGGL((gemm_tn_dma_kernel<WMI, EPI, NJ>), dim3(grid), dim3(256), lds, (hipStream_t)stream,          \
+                           (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, \
+                           (bf16_t*)G, ldg, (const bf16_t*)Fpre, ldfp, colpart);                                         \
     }
     if (Fpre) {
-        if (bm == 64) GM3D_DMA_LAUNCH(1, 2) else GM3D_DMA_LAUNCH(2, 2)
+        if (bm == 64) GM3D_DMA_LAUNCH(1, 2, 3) else GM3D_DMA_LAUNCH(2, 2, 3)
     } else if (G) {
-        if (bm == 64) GM3D_DMA_LAUNCH(1, 1) else GM3D_DMA_LAUNCH(2, 1)
+        if (bm == 64) GM3D_DMA_LAUNCH(1, 1, 3) else GM3D_DMA_LAUNCH(2, 1, 3)
+    } else if (bn == 192) {
+        if (bm == 64) GM3D_DMA_LAUNCH(1, 0, 3) else GM3D_DMA_LAUNCH(2, 0, 3)
+    } else if (bn == 128) {
+        if (bm == 64) GM3D_DMA_LAUNCH(1, 0, 2) else GM3D_DMA_LAUNCH(2, 0, 2)
     } else {
-        if (bm == 64) GM3D_DMA_LAUNCH(1, 0) else GM3D_DMA_LAUNCH(2, 0)
+        if (bm == 64) GM3D_DMA_LAUNCH(1, 0, 4) else GM3D_DMA_LAUNCH(2, 0, 4)
     }
 #undef GM3D_DMA_LAUNCH
     GM3D_CHECK_LAUNCH();
@@ -228,6 +240,12 @@ extern "C" int gm3d_gemm_tn_bf16_dma(const void* A, const void* W, const float* 
                                      int ldc, int bm, gm3d_stream_t stream) {
     if (!C) return GM3D_EINVAL;
     return dma_launch(A, W, bias, C, nullptr, M, N, K, lda, ldw, ldc, 0, bm, stream);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_dmaw(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                                      int ldc, int bm, int bn, gm3d_stream_t stream) {
+    if (!C) return GM3D_EINVAL;
+    return dma_launch(A, W, bias, C, nullptr, M, N, K, lda, ldw, ldc, 0, bm, stream, nullptr, 0, nullptr, bn);
 }
 
 extern "C" int gm3d_gemm_tn_bf16_dma_gelu(const void* A, const void* W, const float* bias, void* F, void* G, int M, int N, int K,

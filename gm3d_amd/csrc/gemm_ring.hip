@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
             src[i] = A + (size_t)am * lda + ((pslot ^ ring_f(row)) << 3);
         } else {
             const int row = 8 * (p - PA) + prow;
-            src[i] = W + (size_t)(n0 + row) * ldw + ((pslot ^ ring_f(row)) << 3);
+            const int wn_ = n0 + row < N ? n0 + row : N - 1;          // columns past N (a ragged last tile): clamped, never stored
+            src[i] = W + (size_t)wn_ * ldw + ((pslot ^ ring_f(row)) << 3);
         }
     }
 #define GM3D_RING_STAGE(ST)                                                                          \
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
     for (int i = 0; i < 4 * WMI; ++i) {
         const int c = tid + 256 * i;
         const int row = c >> 4, nc = (c & 15) * 8;
-        if (m0 + row < M) {
+        if (m0 + row < M && n0 + nc < N) {
             float v[8];
             const float4 x = *reinterpret_cast<const float4*>(cs + row * RCP + nc), y = *reinterpret_cast<const float4*>(cs + row * RCP + nc + 4);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
@@ -205,10 +206,13 @@ static int ring_launch(const void* A, const void* W, const float* bias, void* C,
                        float* stats, void* U16) {
     using namespace gm3d;
     if (!A || !W || (!C && !U) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
-    if (N % RBN || K % RBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
+    // N % 128 != 0 (the 96-wide reconstruction head, P/models_mae_learn_loss.py:169-176): the last column tile is ragged -- W rows
+    // past N are clamped, columns past N never stored; the residual epilogue needs whole tiles
+    if (N % 8 || (U && N % RBN) || K % RBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N)))
+        return GM3D_EUNSUPPORTED;
     if ((((size_t)A | (size_t)W) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / RBN;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + RBN - 1) / RBN;
     if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
     const size_t lds = (size_t)RNBUF * (bm + RBN) * 128;

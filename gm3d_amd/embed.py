@@ -1,6 +1,6 @@
 """Mini-PointNet token embed (Encoder.forward, Point-MAE_SA3D/models_mae_learn_loss.py:868-899) as ONE autograd
-node: three wide GEMMs (hipBLASLt) with every pass between them a hand-written streaming kernel
-(gm3d_amd/csrc/embed.hip), forward and backward.
+node: the wide products on our own MFMA kernels (gemm.mm / gemm.mm_nn: no library GEMM in bf16 mode since round 3) with every
+pass between them a hand-written streaming kernel (gm3d_amd/csrc/embed.hip), forward and backward.
 
     x (rows,3) --[K=3 conv + BN1 + ReLU on the fly]--> a1 (rows,128) --GEMM--> f (rows,256)
       fg = max_k f ; t = fg @ W3[:, :256]^T + b3 (per group) ; y0 = f @ W3[:, 256:]^T
@@ -140,8 +140,8 @@ class EmbedFn(torch.autograd.Function):
         # ---- conv3 on [global | local] ----
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
         W3g, W3l = W3[:, :C2], W3[:, C2:]
-        t = torch.addmm(weight_cache.get(b3, adt), fg, W3g.t())
-        y0 = f @ W3l.t()
+        t = gemm.mm(fg, W3g, _c32(b3))
+        y0 = gemm.mm(f, W3l)
         st = None
         if training:
             nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
@@ -214,7 +214,7 @@ class EmbedFn(torch.autograd.Function):
         _launch("gm3d_group_max_bwd", {"G": BGs, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_bwd, _ptr(dtok),
                 _ptr(arg2), _ptr(dz), BGs, K, C4, dt_id, _stream())
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
-        da2 = dz @ W4
+        da2 = gemm.mm_nn(dz, W4)
         dW4 = splitk_wgrad(dz, a2)
         # BN2 + ReLU: the sums run over the rows that carry a gradient, dy is written for every row
         nrows = lib.gm3d_embed_partial_rows(1, BGs, C3)
@@ -233,12 +233,15 @@ class EmbedFn(torch.autograd.Function):
         # conv3: local part on rows, global part per group
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
         W3g, W3l = W3[:, :C2], W3[:, C2:]
-        df = dy @ W3l
+        bf16 = adt == torch.bfloat16 and gemm.ENABLED
+        if bf16:            # one transposing launch for both halves: rows [0, C2) of W3^T multiply the per-group term, the rest the rows
+            W3T = gemm.transposed(W3)
+        df = gemm.mm(dy, W3T[C2:]) if bf16 else dy @ W3l
         dW3l = splitk_wgrad(dy, f)
         db3 = colsum(dt, torch.float32)
         dta = dt.to(adt)
         dW3g = splitk_wgrad(dta, fg)
-        dfg = dta @ W3g
+        dfg = gemm.mm(dta, W3T[:C2]) if bf16 else dta @ W3g
         dW3 = torch.cat([dW3g, dW3l], dim=1).reshape(w3.shape)
         # max-pool branch joins df; bias grad of conv2
         nrows = lib.gm3d_embed_partial_rows(1, BG, C2)
@@ -248,7 +251,7 @@ class EmbedFn(torch.autograd.Function):
         db2 = _finish(part, nrows, C2)
         # conv2
         W2 = weight_cache.get(w2, adt).reshape(C2, C1)
-        da1 = df @ W2
+        da1 = gemm.mm_nn(df, W2)
         dW2 = splitk_wgrad(df, a1).reshape(w2.shape)
         # layer 1: BN1 + conv(K=3), reductions only
         W1 = _c32(w1.reshape(C1, 3))

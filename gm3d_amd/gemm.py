@@ -141,36 +141,86 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
     return f_out, g_out
 
 
+def linear_tn_dmaw(x, w, bias=None, out=None, bm=128, bn=256):
+    """linear_tn through csrc/gemm_dma.hip with a bm x bn tile (bn = 128 / 192 / 256 columns, N % bn == 0): bit-identical."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_dmaw", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dmaw, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M,
+            N, K, x.stride(0), w.stride(0), out.stride(0), int(bm), int(bn), _stream())
+    return out
+
+
+OWN_KT = (2, 4, 6, 8, 16, 18, 24)      # K / 64 values csrc/gemm.hip is unrolled for
+
+
 def choose(M, N, K):
-    """Which kernel runs the plain product x (M,K) @ w (N,K)^T on MI355X: "lib" (hipBLASLt through torch.mm, TunableOp table),
-    "own" (register-prefetch kernel, csrc/gemm.hip), "ring64" / "ring128" (LDS-DMA ring, csrc/gemm_ring.hip, tile height),
-    "dma64" / "dma128" (192-column LDS-DMA double buffer, csrc/gemm_dma.hip).
-    From the per-shape table profiles/r02_gemm_kbench.txt (tools/gemm_kbench.py); rule: a shape stays on the library only where
-    the tuned library solution is >= 5 % faster than the best hand-written form."""
+    """Which hand-written kernel runs the plain product x (M,K) @ w (N,K)^T on MI355X: "own" (register-prefetch kernel,
+    csrc/gemm.hip), "ring64" / "ring128" (LDS-DMA ring, csrc/gemm_ring.hip, tile height), "dma<bm>x<bn>" (LDS-DMA double buffer
+    with a bm x bn tile, csrc/gemm_dma.hip).  From the per-shape tables profiles/r03_gemm_kbench.txt (tools/gemm_kbench.py).
+    Round 3: NO shape goes to the library any more (round 2 kept a shape there where the tuned hipBLASLt solution was >= 5 %
+    faster): every product of the bf16 step is one of our kernels with a fixed accumulation order -- eager == captured by
+    construction, and the measured path no longer depends on a TunableOp table."""
     if (N, K) == (384, 384):
         return "ring64" if M <= 4096 else "ring128"
     if N == 384 and K in (1024, 1152, 1536):            # long K, three column tiles: the ring's regime
         return "ring64" if M <= 4096 else "ring128"
     if (N, K) == (1152, 384):
-        return "ring128" if M <= 3200 else ("dma64" if M <= 4096 else "dma128") if USE_DMA else "lib"
-    if (N, K) == (128, 256) and M >= 65536:
-        return "ring128"
-    return "lib"
+        return "ring128" if M <= 3200 else ("dma64x192" if M <= 4096 else "dma128x192") if USE_DMA else "own"
+    if M >= 32768:                                       # the mini-PointNet products over the point rows: HBM-bound streams
+        if N % 256 == 0:
+            return "dma128x256"
+        if N % 192 == 0:
+            return "dma128x192"
+        return "dma128x128"
+    if N % 256 == 0 and K <= 512:
+        return "dma64x256"
+    if N == 128:
+        return "dma64x128"
+    if K // 64 in OWN_KT:
+        return "own"
+    return "ring64" if M <= 4096 else "ring128"
 
 
 def mm(x, w, bias=None, out=None):
-    """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names (the library when the operands do not meet the hand-written
-    kernels' layout rules)."""
+    """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names.  Operands that do not meet the hand-written kernels' layout
+    rules (fp32 parity mode, odd widths) go to torch.mm: never on the bf16 step's path (tools/leftover_sites.py lists none)."""
     how = choose(x.shape[0], w.shape[0], w.shape[1]) if supported(x, w) else "lib"
     if how == "own":
         return linear_tn(x, w, bias, out)
     if how.startswith("ring"):
         return linear_tn_ring(x, w, bias, out, bm=int(how[4:]))
     if how.startswith("dma"):
-        return linear_tn_dma(x, w, bias, out, bm=int(how[3:]))
+        bm, bn = how[3:].split("x")
+        return linear_tn_dmaw(x, w, bias, out, bm=int(bm), bn=int(bn))
     y = x @ w.t()
     if bias is not None:
         y = y + bias.to(y.dtype)
+    return y if out is None else out.copy_(y)
+
+
+def transposed(w):
+    """w (N,K) bf16 contiguous -> (K,N) contiguous, one launch of our transpose kernel (N, K % 64 == 0), else torch."""
+    N, K = w.shape
+    if w.dtype == torch.bfloat16 and w.is_contiguous() and N % 64 == 0 and K % 64 == 0 and w.is_cuda:
+        out = torch.empty(K, N, dtype=w.dtype, device=w.device)
+        _launch("gm3d_transpose_bf16_batched", {"batch": 1, "rows": N, "cols": K}, lib.gm3d_transpose_bf16_batched, _ptr(w), _ptr(out),
+                1, N, K, N * K, _stream())
+        return out
+    return w.t().contiguous()
+
+
+def mm_nn(x, w, out=None):
+    """x (M,N) @ w (N,K) -> (M,K): the input gradient dY . W of a Linear / Conv1d(k=1) layer with weight w (N,K).  bf16 operands
+    run as the TN product against a transposed copy of w (one small transposing launch per call: the weights of the layers this
+    serves have 32 K .. 512 K elements); anything else goes to torch.mm."""
+    if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
+            and w.shape[1] % 128 == 0 and w.shape[0] % 64 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+        wt = transposed(w.contiguous())
+        if supported(x, wt):
+            return mm(x, wt, None, out)
+    y = x @ w
     return y if out is None else out.copy_(y)
 
 

@@ -14,6 +14,7 @@ import torch
 from ._capi import lib
 from .embed import _c32, _finish, colsum, splitk_wgrad
 from .fused import weight_cache
+from . import gemm
 from .ops import _launch, _ptr, _stream, _DT
 
 
@@ -29,9 +30,18 @@ def _finish64(part, nrows, ncols):
     return out
 
 
+def _ragged_ok(x2, W):
+    """bf16 rows against a weight whose width is a multiple of 8 but not of 128 (the 96-wide reconstruction head): the ring
+    kernel's ragged last column tile."""
+    return (gemm.ENABLED and x2.is_cuda and x2.dtype == torch.bfloat16 and W.dtype == torch.bfloat16 and W.shape[0] % 8 == 0
+            and W.shape[1] % 64 == 0 and W.stride(1) == 1 and W.stride(0) % 8 == 0 and x2.data_ptr() % 16 == 0 and W.data_ptr() % 16 == 0)
+
+
 class LinearBiasFn(torch.autograd.Function):
-    """y = x @ W^T + b on rows; x (..,K), W (N,K[,1]) fp32 master, b (N) or None; computed in adt.  The bias gradient is our own
-    column-sum kernel: PyTorch's multi-block reduction is not hipGraph-replay-safe on this stack."""
+    """y = x @ W^T + b on rows; x (..,K), W (N,K[,1]) fp32 master, b (N) or None; computed in adt.  bf16: our own MFMA kernels
+    forward and backward (gemm.mm / the ring kernel's ragged tile for widths like 96; input gradient as a TN product against
+    W^T; a width below 128 is zero-padded ONCE for both backward products).  The bias gradient is our own column-sum kernel:
+    PyTorch's multi-block reduction is not hipGraph-replay-safe on this stack."""
 
     @staticmethod
     def forward(ctx, x, w, b, adt):
@@ -39,7 +49,12 @@ class LinearBiasFn(torch.autograd.Function):
             shp = x.shape
             x2 = x.reshape(-1, shp[-1]).to(adt).contiguous()
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
-            y = torch.addmm(weight_cache.get(b, adt), x2, W.t()) if b is not None else x2 @ W.t()
+            if gemm.supported(x2, W):
+                y = gemm.mm(x2, W, _c32(b) if b is not None else None)
+            elif _ragged_ok(x2, W):
+                y = gemm.linear_tn_ring(x2, W, _c32(b) if b is not None else None)
+            else:
+                y = torch.addmm(weight_cache.get(b, adt), x2, W.t()) if b is not None else x2 @ W.t()
             ctx.save_for_backward(x2, w)
             ctx.adt, ctx.shp, ctx.xdt, ctx.has_bias = adt, shp, x.dtype, b is not None
             return y.view(*shp[:-1], w.shape[0])
@@ -51,9 +66,21 @@ class LinearBiasFn(torch.autograd.Function):
             adt = ctx.adt
             dy2 = dy.reshape(-1, dy.shape[-1]).to(adt).contiguous()
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
-            dx = (dy2 @ W).view(ctx.shp).to(ctx.xdt)
-            dW = splitk_wgrad(dy2, x2).reshape(w.shape)
+            N, K = W.shape
+            R = dy2.shape[0]
             db = colsum(dy2, adt) if ctx.has_bias else None
+            if (adt == torch.bfloat16 and N < 128 and K % 128 == 0
+                    and gemm.wgrad_supported(dy2.new_empty(1, R, 128), x2.unsqueeze(0))):
+                # narrow layer (N = 96): dy and W^T zero-padded to one 128-wide tile, shared by both products
+                pad = torch.zeros(R, 128, dtype=adt, device=dy2.device)
+                pad[:, :N] = dy2
+                wt = torch.zeros(K, 128, dtype=adt, device=dy2.device)
+                wt[:, :N] = W.t()
+                dx = gemm.mm(pad, wt).view(ctx.shp).to(ctx.xdt)
+                dW = gemm.wgrad_nt(pad.unsqueeze(0), x2.unsqueeze(0))[0][:N].contiguous().reshape(w.shape)
+                return dx, dW, db, None
+            dx = gemm.mm_nn(dy2, W).view(ctx.shp).to(ctx.xdt)
+            dW = splitk_wgrad(dy2, x2).reshape(w.shape)
             return dx, dW, db, None
 
 
@@ -113,7 +140,7 @@ class PosEmbedFn(torch.autograd.Function):
             _launch("gm3d_lin3_gelu_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_fwd, _ptr(x), _ptr(w0f),
                     _ptr(b0f), _ptr(h), R, C, _DT[adt], _stream())
             W1 = weight_cache.get(w1, adt)
-            out = torch.addmm(weight_cache.get(b1, adt), h, W1.t())
+            out = gemm.mm(h, W1, _c32(b1))
             ctx.save_for_backward(x, h, w0f, b0f, w1)
             ctx.adt, ctx.dims = adt, (B, G, R, C)
             return out.view(B, G, -1)
@@ -128,7 +155,7 @@ class PosEmbedFn(torch.autograd.Function):
             W1 = weight_cache.get(w1, adt)
             dW1 = splitk_wgrad(d, h)
             db1 = colsum(d, adt)
-            dh = (d @ W1).contiguous()
+            dh = gemm.mm_nn(d, W1).contiguous()
             nrows = lib.gm3d_embed_partial_rows(3, R, C)
             part = torch.empty(nrows, 4 * C, dtype=torch.float64, device=x.device)
             _launch("gm3d_lin3_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_bwd, _ptr(dh), _ptr(x),
@@ -152,7 +179,7 @@ class LossPredHeadFn(torch.autograd.Function):
             dev = x.device
             x2 = x.reshape(R, Cin).to(adt).contiguous()
             W0 = weight_cache.get(w0, adt).reshape(C, Cin)
-            y0 = x2 @ W0.t()
+            y0 = gemm.mm(x2, W0)
             t = weight_cache.get(b0, adt).detach().unsqueeze(0).expand(G, C).contiguous()
             st = None
             if training:
@@ -196,7 +223,12 @@ class LossPredHeadFn(torch.autograd.Function):
             d = dout.reshape(R).float().contiguous()
             nout = w1.shape[0]
             # out = a @ wv + mean(b1), wv = mean_rows(W1)
-            dwv = (a.t() @ d.to(adt)).float().contiguous()                           # (C,)  GEMV, not a reduce_kernel
+            # dwv (C,) = a^T d: a weighted column sum in two deterministic stages (was a library GEMV)
+            nrows = lib.gm3d_embed_partial_rows(2, R, C)
+            part = torch.empty(nrows, C, dtype=torch.float32, device=dev)
+            _launch("gm3d_colsum_partial_w", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_colsum_partial_w, _ptr(a), _ptr(d), R, C,
+                    _ptr(part), _DT[adt], _stream())
+            dwv = _finish(part, nrows, C)
             dW1 = torch.empty(w1.shape, dtype=torch.float32, device=dev)
             db1 = torch.empty(nout, dtype=torch.float32, device=dev)
             _launch("gm3d_head_fold_bwd", {"C": C}, lib.gm3d_head_fold_bwd, _ptr(dwv), _ptr(d), R, nout, C, _ptr(dW1), _ptr(db1),
@@ -217,7 +249,7 @@ class LossPredHeadFn(torch.autograd.Function):
                     _ptr(da), _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(mean), _ptr(rstd), _ptr(s1), _ptr(s2),
                     _ptr(dy), _ptr(dt), G, K, C, float(slope), _DT[adt], _stream())
             W0 = weight_cache.get(w0, adt).reshape(C, Cin)
-            dx = (dy @ W0).view(B, L, Cin).to(ctx.xdt)
+            dx = gemm.mm_nn(dy, W0).view(B, L, Cin).to(ctx.xdt)
             dW0 = splitk_wgrad(dy, x2).reshape(w0.shape)
             db0 = colsum(dt, torch.float32)
             return dx, dW0, db0, s2, s1, dW1, db1, None, None, None, None

@@ -272,6 +272,10 @@ int gm3d_colsum_finish_f64(const double *partial, int nrows, int pitch, int ncol
 
 /* partial[row][c] = column sums of a (R,C) matrix in `dtype`; rows = gm3d_embed_partial_rows(2, R, C); C % 8 == 0, 8 <= C <= 2048. */
 int gm3d_colsum_partial(const void *m, int R, int C, float *partial, int dtype, gm3d_stream_t stream);
+/* The same with a per-row weight roww (R) f32 (NULL = 1): partial sums of roww[r] * m[r][c].  Replaces the library GEMV a^T d in
+ * the backward of the loss-prediction head (increase_dim_2 + mean(-1), models_mae_learn_loss.py:152-158,677): fixed summation
+ * order, replay-safe. */
+int gm3d_colsum_partial_w(const void *m, const float *roww, int R, int C, float *partial, int dtype, gm3d_stream_t stream);
 
 /* out (R,C) = GELU(x (R,3) . w (C,3)^T + b): first layer + activation of pos_embed (models_mae_learn_loss.py:104-108). */
 int gm3d_lin3_gelu_fwd(const float *x, const float *w, const float *b, void *out, int R, int C, int dtype,
@@ -376,7 +380,8 @@ int gm3d_gemm_tn_bf16_lna(const void *U16, const float *stats, const float *gamm
 int gm3d_gemm_tile_rows(int M);
 /* The same product as gm3d_gemm_tn_bf16 (bit-identical results) through a four-stage LDS-DMA ring: for long K over few output
  * tiles (fc2, the fc1 / qkv input gradients: N = 384, K = 1152 .. 1536), where one workgroup per CU has to keep more loads in
- * flight than the register-prefetch kernel does.  bm = 64 or 128: tile height. */
+ * flight than the register-prefetch kernel does.  bm = 64 or 128: tile height.  N need only be a multiple of 8 here (a ragged
+ * last column tile: the 96-wide reconstruction head increase_dim_just_network_without_feature, models_mae_learn_loss.py:169-176). */
 int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
                            int bm, gm3d_stream_t stream);
 /* The same products for SHORT K over many tiles (csrc/gemm_dma.hip: 64- or 128-row x 192-column tiles, LDS-DMA double buffer, two
@@ -384,6 +389,12 @@ int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void
  * operands; results bit-identical to gm3d_gemm_tn_bf16 / gm3d_gemm_tn_bf16_ring.  bm = 64 or 128. */
 int gm3d_gemm_tn_bf16_dma(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
                           int bm, gm3d_stream_t stream);
+/* The same kernel with the tile width chosen by the caller: bn = 128, 192 or 256 columns (N % bn == 0).  The 256-column form is
+ * for the mini-PointNet convolutions over the B*G*k = 262,144 point rows and their input gradients (Encoder.second_conv,
+ * models_mae_learn_loss.py:878-883: 256 -> 512, 512 -> 384 and back), which stream A once from HBM; the 128-column form for
+ * first_conv.3's input gradient (256 -> 128, :876) and pos_embed.2's (384 -> 128, :104-108).  Bit-identical to the other forms. */
+int gm3d_gemm_tn_bf16_dmaw(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
+                           int bm, int bn, gm3d_stream_t stream);
 /* ... with the fc1 epilogue of gm3d_gemm_tn_bf16_gelu: F (optional) = bf16(A.W^T), G = GELU(F + bias). */
 int gm3d_gemm_tn_bf16_dma_gelu(const void *A, const void *W, const float *bias, void *F, void *G, int M, int N, int K, int lda,
                                int ldw, int ldf, int ldg, int bm, gm3d_stream_t stream);

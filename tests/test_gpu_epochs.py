@@ -193,7 +193,7 @@ def test_partial_accumulation_window_is_discarded_at_the_epoch_boundary():
             E_, model, ema, opt, args = _pretrain_setup(B, accum=2, drop_path=False)
             torch.manual_seed(5)            # mask noise / augmentation draws: same sequence in both runs
             E._warm.clear()
-            loader = _SnapshotLoader([data[0], data[1], data[stray]], model)
+            loader = _SnapshotLoader([data[i].clone() for i in (0, 1, stray)], model)    # (the augmentation works in place)
             E_.train_one_epoch(model, loader, opt, torch.device("cuda"), 10, None, args=args, model_ema=ema, use_graph=False)
             with torch.no_grad():
                 for t, v in zip(model.buffers(), loader.snap):
@@ -201,7 +201,7 @@ def test_partial_accumulation_window_is_discarded_at_the_epoch_boundary():
             torch.manual_seed(6)
             if use_graph:
                 E._warm[model] = 10 * E.EAGER_WARMUP_ITERS      # capture before the first iteration of the second epoch
-            s = E_.train_one_epoch(model, Loader([data[3], data[4]]), opt, torch.device("cuda"), 11, None, args=args,
+            s = E_.train_one_epoch(model, Loader([data[3].clone(), data[4].clone()]), opt, torch.device("cuda"), 11, None, args=args,
                                    model_ema=ema, use_graph=use_graph)
             assert s["replayed_iters"] == (2 if use_graph else 0)
             ends.append(opt.P.clone())

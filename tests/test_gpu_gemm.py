@@ -230,3 +230,68 @@ def test_gemm_dma_gelu_bwd_equals_register_prefetch_kernel(M, bm):
     assert torch.equal(df0, df1[:M]) and bool((df1[M:] == 3.0).all())
     s0, s1 = cp0.sum(0), cp1.sum(0)
     assert float((s0 - s1).abs().max()) <= 1e-5 * float(s0.abs().max()) * max(1.0, M / 4096)
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 256, 512), (4100, 512, 256), (8192, 384, 1024), (333, 128, 384), (8192, 384, 128), (200, 64, 768),
+                                   (70000, 256, 128)])
+@pytest.mark.parametrize("bm", [64, 128])
+def test_gemm_dma_tile_widths_equal_register_prefetch_kernel(M, K, N, bm):
+    """csrc/gemm_dma.hip with 128- and 256-column tiles (round 3: the mini-PointNet / head products that used to go to the library):
+    every width multiplies in the register-prefetch kernel's order -> bit-identical results, with and without bias, rows past M
+    untouched; and gemm.mm -- whatever kernel the table names -- returns the same bits."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N + bm)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias in (None, b):
+        want = gemm.linear_tn(x, w, bias) if K // 64 in gemm.OWN_KT else gemm.linear_tn_ring(x, w, bias)
+        for bn in (128, 192, 256):
+            if N % bn:
+                continue
+            out = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+            gemm.linear_tn_dmaw(x, w, bias, out=out[:M], bm=bm, bn=bn)
+            assert torch.equal(out[:M], want), bn
+            assert bool((out[M:] == 7.0).all())
+        assert torch.equal(gemm.mm(x, w, bias), want)
+        assert gemm.choose(M, N, K) != "lib"
+        ref = x.float() @ w.float().t() + (bias if bias is not None else 0.0)
+        assert float((want.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("M,K,N", [(8192, 384, 96), (3000, 128, 200), (64, 64, 8), (4096, 384, 136)])
+@pytest.mark.parametrize("bm", [64, 128])
+def test_gemm_ring_ragged_last_column_tile(M, K, N, bm):
+    """The ring kernel with N % 128 != 0 (the 96-wide reconstruction head, P/models_mae_learn_loss.py:169-176): columns [0, N) equal
+    the product against the weight zero-padded to whole tiles (same kernel, same order -> same bits), nothing is stored past column
+    N or row M."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N + bm)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    Np = (N + 127) // 128 * 128
+    wp = torch.zeros(Np, K, device="cuda", dtype=torch.bfloat16)
+    wp[:N] = w
+    bp = torch.zeros(Np, device="cuda")
+    bp[:N] = b
+    for bias, biasp in ((None, None), (b, bp)):
+        want = gemm.linear_tn_ring(x, wp, biasp, bm=bm)[:, :N]
+        out = torch.full((M + 2, N + 8), 5.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn_ring(x, w, bias, out=out[:M, :N], bm=bm)
+        assert torch.equal(out[:M, :N], want)
+        assert bool((out[M:] == 5.0).all()) and bool((out[:, N:] == 5.0).all())
+
+
+def test_gemm_mm_nn_equals_transposed_product():
+    """gemm.mm_nn(x, w) = x @ w for a Linear's input gradient: the TN product against a transposed copy of w -- bits equal to
+    gemm.mm on an explicitly transposed weight, values equal to the fp32 product within one bf16 rounding."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for M, N, K in ((8192, 1024, 384), (102400, 384, 512), (8192, 384, 128), (4096, 256, 128)):
+        x = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+        w = (torch.randn(N, K, device="cuda", generator=g) / N ** 0.5).bfloat16()
+        got = gemm.mm_nn(x, w)
+        assert torch.equal(got, gemm.mm(x, w.t().contiguous()))
+        ref = x.float() @ w.float()
+        assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2

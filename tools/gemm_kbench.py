@@ -9,8 +9,10 @@ E.enable_tuned_gemms()
 dev = torch.device("cuda")
 SHAPES = [(4096, 384, 1152), (4096, 384, 384), (4096, 384, 1536), (4096, 1536, 384), (4096, 1152, 384), (8192, 384, 1152), (8192, 384, 384), (8192, 384, 1536), (8192, 1536, 384), (8192, 1152, 384),
           (3200, 384, 1152), (3200, 384, 384), (3200, 384, 1536), (3200, 1536, 384), (3200, 1152, 384),
-          (262144, 128, 256), (262144, 256, 512), (262144, 512, 384), (262144, 384, 512), (262144, 512, 256), (262144, 256, 128),
-          (8192, 384, 1024), (8192, 1024, 384)]
+          # mini-PointNet over the point rows (forward, input gradients; 102,400 = the student's visible rows)
+          (262144, 128, 256), (262144, 256, 512), (262144, 512, 384), (102400, 512, 384), (102400, 384, 512), (262144, 512, 256), (262144, 256, 128),
+          # per-group / per-token products of the embed and the heads
+          (8192, 256, 512), (8192, 512, 256), (8192, 128, 384), (8192, 384, 128), (8192, 384, 1024), (8192, 1024, 384), (8192, 128, 384)]
 NSET = 4
 
 
@@ -33,19 +35,25 @@ def train(fn, sets, iters=40):
 
 
 if __name__ == "__main__":
+    import sys
+    only_new = "--new" in sys.argv
     for M, K, N in SHAPES:
+        if only_new and M in (4096, 3200) or (only_new and M == 8192 and (K, N) in ((384, 1152), (384, 384), (384, 1536), (1536, 384), (1152, 384))):
+            continue
         nset = NSET if M < 100000 else 2
         sets = [(torch.randn(M, K, device=dev).bfloat16(), (torch.randn(N, K, device=dev) / K ** 0.5).bfloat16(),
                  torch.empty(M, N, device=dev, dtype=torch.bfloat16)) for _ in range(nset)]
-        t_lib = train(lambda x, w, o: torch.mm(x, w.t(), out=o), sets)
-        t_own = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
-        t_r64 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=64), sets)
-        t_r128 = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=128), sets)
         fl = 2.0 * M * K * N
-        dma = ""
-        if N % 192 == 0:
-            t_d64 = train(lambda x, w, o: gemm.linear_tn_dma(x, w, out=o, bm=64), sets)
-            t_d128 = train(lambda x, w, o: gemm.linear_tn_dma(x, w, out=o, bm=128), sets)
-            dma = "   dma64 %7.1f us x%.2f   dma128 %7.1f us x%.2f" % (t_d64, t_lib / t_d64, t_d128, t_lib / t_d128)
-        print("M=%6d K=%4d N=%4d   hipBLASLt %7.1f us %5.0f TF/s   own %7.1f us %5.0f TF/s x%.2f   ring64 %7.1f us x%.2f   ring128 %7.1f us x%.2f" %
-              (M, K, N, t_lib, fl / t_lib / 1e6, t_own, fl / t_own / 1e6, t_lib / t_own, t_r64, t_lib / t_r64, t_r128, t_lib / t_r128) + dma)
+        res = {"lib": train(lambda x, w, o: torch.mm(x, w.t(), out=o), sets)}
+        if K // 64 in gemm.OWN_KT:
+            res["own"] = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
+        for bm in (64, 128):
+            res["ring%d" % bm] = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=bm), sets)
+            for bn in (128, 192, 256):
+                if N % bn == 0:
+                    res["dma%dx%d" % (bm, bn)] = train(lambda x, w, o: gemm.linear_tn_dmaw(x, w, out=o, bm=bm, bn=bn), sets)
+        best = min((v, k) for k, v in res.items() if k != "lib")
+        hbm = 2.0 * (M * K + M * N + N * K) / 1e6          # MB: A once, C once, W once
+        print("M=%6d K=%4d N=%4d  lib %7.1f us | " % (M, K, N, res["lib"]) + "  ".join("%s %.1f" % (k, v) for k, v in res.items() if k != "lib")
+              + " | best %s %.1f us = %.0f TF/s, %.2f TB/s of A+C+W, x%.2f vs lib; table says %s"
+              % (best[1], best[0], fl / best[0] / 1e6, hbm / best[0], res["lib"] / best[0], gemm.choose(M, N, K)))
