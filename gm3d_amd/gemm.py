@@ -168,19 +168,17 @@ def choose(M, N, K):
         return "ring64" if M <= 4096 else "ring128"
     if (N, K) == (1152, 384):
         return "ring128" if M <= 3200 else ("dma64x192" if M <= 4096 else "dma128x192") if USE_DMA else "own"
+    if K == 384 and N % 192 == 0 and N > 384 and M < 32768:
+        return ("dma64x192" if M <= 4096 else "dma128x192") if USE_DMA else "own"
     if M >= 32768:                                       # the mini-PointNet products over the point rows: HBM-bound streams
-        if N % 256 == 0:
-            return "dma128x256"
-        if N % 192 == 0:
-            return "dma128x192"
+        # two workgroups per CU with one 64-KiB stage each in flight beat every deeper / wider form measured (r03 table:
+        # 128x128 142 us vs 128x256 145, ring128 174, register prefetch 174 at 262144 x 256 -> 512)
+        return "dma128x192" if N % 192 == 0 else "dma128x128"
+    if (N, K) == (256, 512) or (N, K) == (128, 384):    # per-group / per-token input gradients: few tiles, longer K
+        return "ring64"
+    if N == 1024:
         return "dma128x128"
-    if N % 256 == 0 and K <= 512:
-        return "dma64x256"
-    if N == 128:
-        return "dma64x128"
-    if K // 64 in OWN_KT:
-        return "own"
-    return "ring64" if M <= 4096 else "ring128"
+    return "dma64x128"
 
 
 def mm(x, w, bias=None, out=None):
