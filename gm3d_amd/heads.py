@@ -197,6 +197,8 @@ class LossPredHeadFn(torch.autograd.Function):
             a = torch.empty(R, C, dtype=adt, device=dev)
             _launch("gm3d_bn_bcast_apply_relu", {"G": G, "K": K, "C": C, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu,
                     _ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(a), G, K, C, float(slope), _DT[adt], _stream())
+            if meta.get("act_taps") is not None:          # a test records the LeakyReLU's sign pattern (leaky keeps the sign)
+                meta["act_taps"].append(a.detach() > 0)
             W1 = _c32(w1.reshape(w1.shape[0], C))
             nout = w1.shape[0]
             wv, wv_t, bm = torch.empty(C, **f32), torch.empty(C, dtype=adt, device=dev), torch.empty(1, **f32)

@@ -34,6 +34,13 @@ from .hierarchical_group import HierarchicalGroup
 
 FUSED_EMBED0 = True
 FUSED_LAYERNORM = True
+ACT_TAPS = None           # tests set this to a list: the sign pattern (pre-activation > 0) of every ReLU / LeakyReLU of a grad-enabled
+#                           forward on the per-op path, in call order (six token-embed ReLUs, the loss head's LeakyReLU, two
+#                           token-propagation ReLUs)
+POOL_TAPS = None          # tests set this to a list: every max-pool of a grad-enabled TokenEmbed.forward (per-op path) appends its
+#                           winner weights (groups, k, C): 1 at the maximum, 1/n at each of n exactly tied maxima -- how
+#                           torch.amax's backward shares the gradient; the discrete decisions a gradient comparison has to share
+#                           (tests/test_gpu_m2ae.py)
 FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
 
 
@@ -112,6 +119,8 @@ def _lin(x, conv, bn=None, act=False):
     y = _linear(x, conv.weight, conv.bias)
     if bn is not None:
         y = bn(y)
+    if act and ACT_TAPS is not None and torch.is_grad_enabled():
+        ACT_TAPS.append(y.detach() > 0)
     return F.relu(y) if act else y
 
 
@@ -159,6 +168,10 @@ class TokenEmbed(nn.Module):
         fg = f.view(B * G, k, -1).amax(dim=1, keepdim=True).expand(-1, k, -1)
         y = torch.cat([fg, f.view(B * G, k, -1)], dim=-1).reshape(B * G * k, -1)
         y = _lin(_lin(y, self.second_conv[0], self.second_conv[1], True), self.second_conv[3])
+        if POOL_TAPS is not None and torch.is_grad_enabled():
+            for t in (f.detach().view(B * G, k, -1), y.detach().view(B * G, k, self.out_c)):
+                win = (t == t.amax(dim=1, keepdim=True)).to(t.dtype)
+                POOL_TAPS.append(win / win.sum(dim=1, keepdim=True))
         return y.view(B * G, k, self.out_c).amax(dim=1).view(B, G, self.out_c)
 
 
@@ -328,6 +341,7 @@ class PointM2AE(nn.Module):
             from . import heads
             meta = {"adt": heads._adt(), "training": h[1].training, "eps": h[1].eps, "momentum": h[1].momentum,
                     "slope": h[2].negative_slope, "grad": torch.is_grad_enabled()}
+            meta["act_taps"] = ACT_TAPS if torch.is_grad_enabled() else None
             loss_pred = heads.LossPredHeadFn.apply(xc, h[0].weight, h[0].bias, h[1].weight, h[1].bias, h[3].weight, h[3].bias,
                                                    h[1].running_mean, h[1].running_var, h[1].num_batches_tracked, meta)
         else:
@@ -376,7 +390,7 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
     from . import heads
     loss_learn = heads.rank_loss(pred, target)
     return {"loss": lo["Chamfer_mean"] + loss_learn, "loss_chfr": lo["Chamfer_mean"], "loss_learn": loss_learn, "mask": masked,
-            "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"]}
+            "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"], "rec": out["rec"]}
 
 
 def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None, augment=True):

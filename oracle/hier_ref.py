@@ -63,14 +63,39 @@ def _ln(sd, name, x):
     return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5)
 
 
-def _embed(sd, p, groups, training):
+class _Signs:
+    """The sign patterns of the activations of another run, consumed in call order (None: decide here)."""
+
+    def __init__(self, signs):
+        self.signs, self.at = signs, 0
+
+    def act(self, x, slope=0.0):
+        if self.signs is None:
+            return torch.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
+        s = self.signs[self.at].reshape(x.shape)
+        self.at += 1
+        return torch.where(s, x, x * slope)
+
+
+def _pool(t, win):
+    """max over dim 1 of (groups, k, C); with win (groups, k, C) -- 1 at the winner, 1/n at each of n tied winners -- the winner
+    is TAKEN from win instead of decided here (a test injects the decisions of the run it compares with: an argmax is a
+    discontinuity of the gradient, and exact ties do occur: torch.amax shares the gradient between them)."""
+    if win is None:
+        return t.max(dim=1)[0]
+    return (t * win.to(t.dtype)).sum(dim=1)
+
+
+def _embed(sd, p, groups, training, pool_idx=None, signs=None):
+    signs = signs or _Signs(None)
     B, G, k, C = groups.shape
     x = groups.reshape(-1, C)
-    f = _conv(sd, p + ".first_conv.3", torch.relu(_bn(sd, p + ".first_conv.1", _conv(sd, p + ".first_conv.0", x), training)))
+    f = _conv(sd, p + ".first_conv.3", signs.act(_bn(sd, p + ".first_conv.1", _conv(sd, p + ".first_conv.0", x), training)))
     f = f.view(B * G, k, -1)
-    y = torch.cat([f.max(dim=1, keepdim=True)[0].expand(-1, k, -1), f], dim=2).reshape(B * G * k, -1)
-    y = _conv(sd, p + ".second_conv.3", torch.relu(_bn(sd, p + ".second_conv.1", _conv(sd, p + ".second_conv.0", y), training)))
-    return y.view(B * G, k, -1).max(dim=1)[0].view(B, G, -1)
+    i0, i1 = (None, None) if pool_idx is None else pool_idx
+    y = torch.cat([_pool(f, i0).unsqueeze(1).expand(-1, k, -1), f], dim=2).reshape(B * G * k, -1)
+    y = _conv(sd, p + ".second_conv.3", signs.act(_bn(sd, p + ".second_conv.1", _conv(sd, p + ".second_conv.0", y), training)))
+    return _pool(y.view(B * G, k, -1), i1).view(B, G, -1)
 
 
 def _attention(sd, p, x, blocked, H):
@@ -107,9 +132,12 @@ def far_mask(center, radius):
     return d2 >= (r * r)
 
 
-def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=None):
+def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=None, pool_idx=None, act_signs=None):
     """sd: the state dict, fp32 -- or fp64 for a high-precision run of the same computation (grouping, masks and the 3-NN search
-    stay fp32: they are index decisions the product makes in fp32 as well)."""
+    stay fp32: they are index decisions the product makes in fp32 as well).  pool_idx: six (groups, k, C) weight tensors, the winners
+    of the two max-pools of each level's token embed in call order; act_signs: the nine ReLU / LeakyReLU sign patterns in call
+    order (decisions injected by a test; None: decided here)."""
+    signs = _Signs(act_signs)
     H = cfg["num_heads"]
     dt = sd["mask_token"].dtype
     nbs, centers, idxs = group if group is not None else hierarchical_group(pts, cfg["num_groups"], cfg["group_sizes"])
@@ -123,10 +151,10 @@ def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=
     enc, prev = [], None
     for i in range(3):
         if i == 0:
-            tok = _embed(sd, "token_embed.0", nbs[0], training)
+            tok = _embed(sd, "token_embed.0", nbs[0], training, None if pool_idx is None else pool_idx[0:2], signs)
         else:
             feats = torch.stack([prev[b][idxs[i][b]] for b in range(B)])          # (B,G,k,C)
-            tok = _embed(sd, "token_embed.%d" % i, feats, training)
+            tok = _embed(sd, "token_embed.%d" % i, feats, training, None if pool_idx is None else pool_idx[2 * i:2 * i + 2], signs)
         if taps is not None and tok.requires_grad:       # diagnostics: the level's embedded tokens, gradient retained
             tok.retain_grad()
             taps["tok%d" % i] = tok
@@ -141,7 +169,7 @@ def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=
     xc = torch.where(vis2[..., None], x2, sd["mask_token"].expand(B, x2.shape[1], -1))
     xc = _stack(sd, "h_decoder.0", cfg["decoder_depths"][0], xc, _posmlp(sd, "decoder_pos_embeds.0", centers[2]), None, H)
     h = xc.reshape(-1, xc.shape[-1])
-    h = F.leaky_relu(_bn(sd, "loss_pred_head.1", _conv(sd, "loss_pred_head.0", h), training), 0.2)
+    h = signs.act(_bn(sd, "loss_pred_head.1", _conv(sd, "loss_pred_head.0", h), training), 0.2)
     loss_pred = _conv(sd, "loss_pred_head.3", h).mean(dim=-1).view(B, -1)
     x1 = torch.where(vis1[..., None], _ln(sd, "encoder_norms.1", enc[1]), torch.zeros((), dtype=dt))
     # token propagation: 3 nearest coarse centres, inverse squared distance weights
@@ -150,7 +178,7 @@ def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=
     near = torch.stack([xc[b][nn_idx[b]] for b in range(B)])                       # (B,256,3,384)
     y = torch.cat([x1, (near * w[..., None]).sum(dim=2)], dim=-1).reshape(B * x1.shape[1], -1)
     for j in range(2):
-        y = torch.relu(_bn(sd, "token_prop.0.mlp_bns.%d" % j, _conv(sd, "token_prop.0.mlp_convs.%d" % j, y), training))
+        y = signs.act(_bn(sd, "token_prop.0.mlp_bns.%d" % j, _conv(sd, "token_prop.0.mlp_convs.%d" % j, y), training))
     x1 = _stack(sd, "h_decoder.1", cfg["decoder_depths"][1], y.view(B, x1.shape[1], -1), _posmlp(sd, "decoder_pos_embeds.1", centers[1]),
                 None, H)
     x1 = _ln(sd, "decoder_norm", x1)
@@ -158,10 +186,15 @@ def m2ae_forward(sd, pts, mask_coarse, training=True, cfg=CFG, group=None, taps=
     return {"rec": rec, "loss_pred": loss_pred, "masks": masks, "group": (nbs, centers, idxs), "features": x2}
 
 
-def m2ae_losses(rec, nbs, idxs, masks):
+def m2ae_losses(rec, nbs, idxs, masks, nn_idx=None):
+    """nn_idx = (idx1 (P,k1), idx2 (P,k1)) int64: the nearest-neighbour choices of both Chamfer directions, injected by a test (the
+    fp64 run takes the fp32 run's: an argmin is a discontinuity of the gradient); None: decided here."""
     B, G1, k1, _ = rec.shape
     a, b = rec.reshape(B * G1, k1, 3), nbs[1].reshape(B * G1, k1, 3).to(rec.dtype)
-    if rec.dtype == torch.float32:
+    if nn_idx is not None:
+        pair = (a[:, :, None, :] - b[:, None, :, :]).pow(2).sum(-1)
+        d = torch.gather(pair, 2, nn_idx[0].unsqueeze(2)).squeeze(2) + torch.gather(pair, 1, nn_idx[1].unsqueeze(1)).squeeze(1)
+    elif rec.dtype == torch.float32:
         d = ops.ChamferDistanceL2()(a, b)                                                       # per point: d1 + d2
     else:                                                                                       # the same quantity in fp64
         pair = (a[:, :, None, :] - b[:, None, :, :]).pow(2).sum(-1)
@@ -199,18 +232,27 @@ def ranking_loss(pred, target):
     return loss.sum() / (pos | neg).sum()
 
 
-def m2ae_pretrain_forward(sd, sd_teacher, pts, epoch, total_epoch, noise, cfg=CFG, mask=None, taps=None):
-    """mask: use this coarse mask instead of deriving it from the teacher (the fp64 run of a test takes the fp32 run's mask)."""
+def m2ae_pretrain_forward(sd, sd_teacher, pts, epoch, total_epoch, noise, cfg=CFG, mask=None, taps=None, decisions=None):
+    """mask: use this coarse mask instead of deriving it from the teacher (the fp64 run of a test takes the fp32 run's mask).
+    decisions (optional dict): the DISCRETE choices of another run of the same computation, taken over instead of made here, so
+    that two runs in different arithmetic differentiate the same piecewise-smooth branch --
+      "pool_idx"    the six max-pool winners of the token embeds (m2ae_forward),
+      "act_signs"   the nine ReLU / LeakyReLU sign patterns (m2ae_forward),
+      "nn_idx"      the Chamfer nearest-neighbour choices (m2ae_losses),
+      "rank_target" (B,64): the per-token target whose ORDER decides the sign pattern of the ranking loss (ranking_loss)."""
+    decisions = decisions or {}
     with torch.no_grad():
         group = hierarchical_group(pts, cfg["num_groups"], cfg["group_sizes"])
         t = m2ae_forward(sd_teacher, pts, None, training=False, cfg=cfg, group=group)
         if mask is None:
             mask = guided_mask(t["loss_pred"].float(), noise, cfg["mask_ratio"], epoch, total_epoch)
-    out = m2ae_forward(sd, pts, mask, training=True, cfg=cfg, group=group, taps=taps)
-    loss_cd, matrix, cd = m2ae_losses(out["rec"], group[0], group[2], out["masks"])
+    out = m2ae_forward(sd, pts, mask, training=True, cfg=cfg, group=group, taps=taps, pool_idx=decisions.get("pool_idx"),
+                       act_signs=decisions.get("act_signs"))
+    loss_cd, matrix, cd = m2ae_losses(out["rec"], group[0], group[2], out["masks"], nn_idx=decisions.get("nn_idx"))
     n_mask = int(mask[0].sum())
     ids = torch.stack([torch.nonzero(mask[b]).flatten() for b in range(pts.shape[0])])              # (B,n_mask) ascending
     assert ids.shape[1] == n_mask
-    loss_learn = ranking_loss(torch.gather(out["loss_pred"], 1, ids), torch.gather(matrix.detach(), 1, ids))
+    rank_target = decisions["rank_target"].to(matrix.dtype) if "rank_target" in decisions else matrix.detach()
+    loss_learn = ranking_loss(torch.gather(out["loss_pred"], 1, ids), torch.gather(rank_target, 1, ids))
     return {"loss": loss_cd + loss_learn, "loss_chfr": loss_cd, "loss_learn": loss_learn, "mask": mask, "rec": out["rec"],
             "loss_pred": out["loss_pred"], "teacher_loss_pred": t["loss_pred"], "matrix": matrix, "features": out["features"]}

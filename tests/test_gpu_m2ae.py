@@ -32,17 +32,25 @@ def test_radius_mask_bits_kernel():
         assert torch.equal(ops.radius_mask_bits(c.cuda(), None, radius), ops.pack_mask(HR.far_mask(c, radius).cuda()))
 
 
-# max-pool argmax choices and the sign decisions of the ranking loss are discontinuities: a near-tie that fp32 on the GPU resolves
-# differently from fp64 moves O(1e-3) of a gradient between two rows (seen on about half of the seeds tried: tools/m2ae_grad_diag.py
-# shows e.g. exactly two masked level-1 tokens trading 2.9e-6 of gradient).  These seeds take the same decisions on both sides.
-@pytest.mark.parametrize("epoch,seed", [(0, 31), (200, 223), (200, 230)])
-def test_m2ae_forward_backward_against_oracle(epoch, seed):
+# Max-pool winners (including EXACT ties, which do occur: torch.amax shares the gradient between tied maxima, a plain argmax does
+# not), ReLU / LeakyReLU sign patterns (a BatchNorm bias gradient in the loss head is a sum over only B*64 rows: ONE
+# pre-activation within 1e-5 of zero moves it by 1 %), Chamfer nearest neighbours, the guided mask and the sign pattern of the
+# ranking loss are DISCRETE decisions: a
+# near-tie that fp32 on the GPU resolves differently from fp32 / fp64 on the CPU puts the two runs on different smooth branches, and
+# their gradients then differ by O(1e-3) in a few rows although every kernel is right (about half of all seeds: round 2 hand-picked
+# seeds without such a flip).  Now the oracle TAKES the product's decisions (oracle/hier_ref.py `decisions=`; the product exposes
+# them: point_m2ae.POOL_TAPS, its reconstruction, its per-token target), so every seed compares the same branch and a wrong backward
+# kernel cannot hide behind "a decision flipped".  The decision logic itself is checked separately: guided mask recomputed by the
+# oracle from the product's scores, argmax / argmin / grouping kernels bit-exact in their own tests.  12 CONSECUTIVE seeds.
+def _compare_with_oracle(seed):
+    """-> rows (name, e_prod, e_cpu, zero_gradient) for every parameter with a gradient, after the forward checks."""
     from gm3d_amd import engine_pretrain as E
     from gm3d_amd import point_m2ae as P
     from oracle import hier_ref as HR
     from oracle import model_ref as R
     from oracle import ops as oracle_ops
     oracle_ops.build()
+    epoch = 0 if seed % 2 == 0 else 200          # both branches of the guided mask (len_loss = 0 / > 0)
     B, total = 2, 300
     pts = clouds.gaussian(B, 2048, seed=seed)
     noise = torch.rand(B, 64, generator=torch.Generator().manual_seed(5))
@@ -56,42 +64,67 @@ def test_m2ae_forward_backward_against_oracle(epoch, seed):
     model = model.cuda().train()
     ema = E.ModelEma(model, 0.999)
     ema.ema.load_state_dict(teacher_sd)
-    out = P.pretrain_forward(model, ema.ema, pts.cuda(), epoch, total, mask_noise=noise.cuda())
+    P.POOL_TAPS, P.ACT_TAPS = [], []
+    try:
+        out = P.pretrain_forward(model, ema.ema, pts.cuda(), epoch, total, mask_noise=noise.cuda())
+        pool_idx, act_signs = [t.cpu() for t in P.POOL_TAPS], [t.cpu() for t in P.ACT_TAPS]
+    finally:
+        P.POOL_TAPS = P.ACT_TAPS = None
+    assert len(pool_idx) == 6 and len(act_signs) == 9
     out["loss"].backward()
-    ref = HR.m2ae_pretrain_forward(sd, teacher_sd, pts, epoch, total, noise)
+    # the product's decisions
+    mask = out["mask"].cpu()
+    G1, k1 = out["rec"].shape[1], out["rec"].shape[2]
+    group = HR.hierarchical_group(pts)
+    rec_cpu = out["rec"].detach().float().cpu().reshape(B * G1, k1, 3)
+    _, _, i1, i2 = oracle_ops.chamfer(rec_cpu, group[0][1].reshape(B * G1, k1, 3).float())    # == the product's kernel, bit for bit
+    decisions = {"pool_idx": pool_idx, "act_signs": act_signs, "nn_idx": (i1.long(), i2.long()),
+                 "rank_target": out["matrix"].detach().float().cpu()}
+    ref = HR.m2ae_pretrain_forward(sd, teacher_sd, pts, epoch, total, noise, mask=mask, decisions=decisions)
     ref["loss"].backward()
+    # decision logic: the teacher's scores agree, and the oracle's mask rule applied to the PRODUCT's scores gives the product's mask
     assert _rel(out["teacher_loss_pred"], ref["teacher_loss_pred"]) <= 2e-5
-    assert torch.equal(out["mask"].cpu(), ref["mask"]) and int(ref["mask"][0].sum()) == 52
+    want_mask = HR.guided_mask(out["teacher_loss_pred"].detach().float().cpu(), noise, HR.CFG["mask_ratio"], epoch, total)
+    assert torch.equal(mask, want_mask) and int(mask[0].sum()) == 52
     assert _rel(out["matrix"], ref["matrix"]) <= 2e-5
     for k in ("loss_chfr", "loss_learn", "loss"):
         assert _rel(out[k], ref[k]) <= 2e-5, (k, float(out[k]), float(ref[k]))
     # Gradients.  Several are ill-conditioned in fp32 (weights in front of a BatchNorm over 16k-1M rows: a small difference of large
     # sums; biases there have an exactly zero gradient), so "within 5e-5" is not a meaningful bar for them on EITHER side.  The
-    # same computation in fp64 is the truth; the product must be as close to it as the fp32 CPU restatement is (x3), or 5e-5.
+    # same computation in fp64 -- same decisions -- is the truth; the product must be as close to it as the fp32 CPU restatement
+    # is (x3), or 5e-5.
     sd64 = {k: (v.detach().double().requires_grad_(True) if v.dtype.is_floating_point else v.detach()) for k, v in sd.items()}
     t64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in teacher_sd.items()}
-    ref64 = HR.m2ae_pretrain_forward(sd64, t64, pts, epoch, total, noise, mask=ref["mask"])
+    ref64 = HR.m2ae_pretrain_forward(sd64, t64, pts, epoch, total, noise, mask=mask, decisions=decisions)
     ref64["loss"].backward()
     gscale = max(float(t.grad.abs().max()) for t in sd64.values() if torch.is_tensor(t) and t.grad is not None)
-    bad, n = {}, 0
+    rows = []
     for name, p in model.named_parameters():
         g64, g32 = sd64[name].grad, sd[name].grad
         if p.grad is None:
             assert g64 is None or float(g64.abs().max()) <= 1e-9 * gscale, name
             continue
-        n += 1
         scale = max(float(g64.abs().max()), 1e-4 * gscale)
         e_prod = float((p.grad.detach().cpu().double() - g64).abs().max()) / scale
         e_cpu = float((g32.double() - g64).abs().max()) / scale
-        if float(g64.abs().max()) <= 1e-9 * gscale:
+        rows.append((name, e_prod, e_cpu, float(g64.abs().max()) <= 1e-9 * gscale))
+    return rows
+
+
+@pytest.mark.parametrize("seed", list(range(20, 32)))
+def test_m2ae_forward_backward_against_oracle(seed):
+    rows = _compare_with_oracle(seed)
+    bad = {}
+    for name, e_prod, e_cpu, zero in rows:
+        if zero:
             # an exactly zero gradient (a bias in front of a BatchNorm): what either side reports is the rounding residue of a
-            # sum of cancelling terms, whose size depends on the summation order only -- bar: 1e-7 of the largest gradient
-            if e_prod > 1e-3:
+            # sum of cancelling terms, whose size depends on the summation order only -- bar: 3e-7 of the largest gradient
+            if e_prod > max(3e-3, 3.0 * e_cpu):
                 bad[name] = (e_prod, e_cpu)
         elif e_prod > max(5e-5, 3.0 * e_cpu):
             bad[name] = (e_prod, e_cpu)
     assert not bad, sorted(bad.items(), key=lambda kv: -kv[1][0])[:8]
-    assert n > 150
+    assert len(rows) > 150
 
 
 def test_m2ae_bf16_step_runs_and_learns():
