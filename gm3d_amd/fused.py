@@ -173,6 +173,11 @@ def _attention_fwd(qkv, B, T, H, scale, out=None):
     if out is None:
         out = torch.empty(B * T, H * 64, dtype=qkv.dtype, device=qkv.device)
     lse = torch.empty(B, H, T, dtype=torch.float32, device=qkv.device)
+    if T > 128:      # more tokens than one workgroup's LDS images hold (cfgs/config_3.yaml: 256 groups): the flash-style kernel of
+        #              the hierarchical encoder with no mask (T <= 512; same qkv / out / lse layouts)
+        _launch("gm3d_attention_masked_fwd", {"B": B, "T": T, "H": H, "HD": 64, "dtype": str(qkv.dtype)}, lib.gm3d_attention_masked_fwd,
+                _ptr(qkv), None, _ptr(out), _ptr(lse), B, T, H, 64, float(scale), _DT[qkv.dtype], _stream())
+        return out, lse
     _launch("gm3d_attention_fwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_fwd, _ptr(qkv),
             _ptr(out), _ptr(lse), B, T, H, float(scale), _DT[qkv.dtype], _stream())
     return out, lse
@@ -200,6 +205,10 @@ def attention_qkv_supported(h, wqkv, T, H):
 def _attention_bwd(qkv, out, dout, lse, B, T, H, scale, dqkv=None):
     if dqkv is None:
         dqkv = torch.empty_like(qkv)
+    if T > 128:
+        _launch("gm3d_attention_masked_bwd", {"B": B, "T": T, "H": H, "HD": 64, "dtype": str(qkv.dtype)}, lib.gm3d_attention_masked_bwd,
+                _ptr(qkv), None, _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, H, 64, float(scale), _DT[qkv.dtype], _stream())
+        return dqkv
     _launch("gm3d_attention_bwd", {"B": B, "T": T, "H": H, "dtype": str(qkv.dtype)}, lib.gm3d_attention_bwd, _ptr(qkv),
             _ptr(out), _ptr(dout), _ptr(lse), _ptr(dqkv), B, T, H, float(scale), _DT[qkv.dtype], _stream())
     return dqkv

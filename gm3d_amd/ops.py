@@ -308,7 +308,11 @@ class _Attention(torch.autograd.Function):
 
 
 def attention(qkv, num_heads, scale):
-    """qkv (B,T,3*H*64) = output of the qkv Linear (timm layout (B,T,3,H,64)) -> (B,T,H*64)."""
+    """qkv (B,T,3*H*64) = output of the qkv Linear (timm layout (B,T,3,H,64)) -> (B,T,H*64).  T <= 128: one workgroup per (cloud,
+    head) with the whole head in LDS; 128 < T <= 512 (cfgs/config_3.yaml: 256 groups): the flash-style kernel of the hierarchical
+    encoder without a mask."""
+    if qkv.shape[1] > 128:
+        return _AttentionMasked.apply(qkv, None, num_heads, scale)
     return _Attention.apply(qkv, num_heads, scale)
 
 

@@ -44,8 +44,8 @@ class PointTransformer(nn.Module):
         self.group_size = _cfg(config, "group_size")
         self.num_group = _cfg(config, "num_group")
         self.encoder_dims = _cfg(config, "encoder_dims")
-        if self.num_group + 1 > 128:
-            raise NotImplementedError("the HIP attention core holds at most 128 tokens (cls + num_group)")
+        if self.num_group + 1 > 512:
+            raise NotImplementedError("the HIP attention kernels hold at most 512 tokens (cls + num_group)")
 
         self.group_divider = Group(num_group=self.num_group, group_size=self.group_size)
         self.encoder = Encoder(encoder_channel=self.encoder_dims)

@@ -433,7 +433,10 @@ int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
  * qkv (B,T,3,H,HD) as the qkv Linear emits it, HD in {16,32,64}, T <= 512; mask (B,T,ceil(T/32)) uint32 bitset, bit (j&31) of
  * word j>>5 of row i set = query i must not attend to key j (NULL: no mask); the mask must be symmetric.  out (B,T,H*HD), lse
  * (B,H,T) f32 (0 for a query with no allowed key, whose output and gradients are zero).  dtype GM3D_BF16: flash-style MFMA
- * kernels; GM3D_F32: exact fp32 kernels (parity mode). */
+ * kernels; GM3D_F32: exact fp32 kernels (parity mode).  bf16 keeps the head in LDS: the forward needs (2*32*ceil(T/32) + 128) *
+ * (2 HD + 16) bytes, the backward 4*32*ceil(T/32) * (2 HD + 16) + 8*32*ceil(T/32), at most 160 KiB -- i.e. T <= 512 for HD <= 32
+ * and, for HD = 64, T <= 480 forward / T <= 256 backward (GM3D_EUNSUPPORTED beyond).  With mask = NULL and HD = 64 these are also
+ * the attention of the Point-MAE models for more than 128 tokens (cfgs/config_3.yaml: 256 groups). */
 /* The bitset mask of one level of the hierarchical encoder: bits (B,G,ceil(G/32)), bit j of row i set iff token i or token j is
  * not visible (vis (B,G) bytes, NULL = all visible) or their centres (B,G,3) are >= radius apart (radius <= 0: no radius test). */
 int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float radius, int B, int G, unsigned *bits,

@@ -243,3 +243,32 @@ def test_colsum_wide(R, C):
         got = embed.colsum(m, dt)
         want = m.double().sum(0)
         assert float((got.double() - want).abs().max()) <= 2e-6 * float(m.double().abs().sum(0).max())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("T", [129, 256, 257, 512])
+def test_attention_beyond_128_tokens(gops, dtype, T):
+    """ops.attention for 128 < T <= 512 (cfgs/config_3.yaml: 256 groups of 8; cls + 256 in fine-tuning): routed to the flash-style
+    kernel of the hierarchical encoder with a NULL mask.  Forward and input gradient against an fp64 torch softmax attention;
+    fp32: 1e-5, bf16: one rounding of the operands and of the output (2e-2 / 3e-2 of the tensor scale)."""
+    B, H, hd = 3, 6, 64
+    if dtype == torch.bfloat16 and T > 256:
+        # head_dim 64 in bf16: the backward keeps q, k, v, dO of the head in LDS (4 x T x 144 B): T <= 256; the C ABI says so
+        from gm3d_amd._capi import Gm3dError
+        with pytest.raises(Gm3dError):
+            q = torch.zeros(1, T, 3 * H * hd, device="cuda", dtype=dtype, requires_grad=True)
+            gops.attention(q, H, hd ** -0.5).sum().backward()
+        return
+    g = torch.Generator(device="cuda").manual_seed(T)
+    qkv = (torch.randn(B, T, 3 * H * hd, device="cuda", generator=g) * 0.7).to(dtype).requires_grad_(True)
+    dout = torch.randn(B, T, H * hd, device="cuda", generator=g).to(dtype)
+    out = gops.attention(qkv, H, hd ** -0.5)
+    out.backward(dout)
+    q64 = qkv.detach().double().requires_grad_(True)
+    q, k, v = q64.view(B, T, 3, H, hd).permute(2, 0, 3, 1, 4)
+    ref = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1) @ v
+    ref = ref.transpose(1, 2).reshape(B, T, H * hd)
+    ref.backward(dout.double())
+    tol_o, tol_g = (1e-5, 1e-5) if dtype == torch.float32 else (2e-2, 3e-2)
+    assert float((out.double() - ref).abs().max()) <= tol_o * float(ref.abs().max())
+    assert float((qkv.grad.double() - q64.grad).abs().max()) <= tol_g * float(q64.grad.abs().max())

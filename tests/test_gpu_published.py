@@ -204,3 +204,37 @@ def test_bf16_graph_replay_matches_eager(M):
         lg.append(float(o["loss"] + o["loss_learn"]))
     assert all(np.isfinite(le)) and le == lg, (le, lg)             # exact: deterministic kernels, same operands
     assert all(torch.equal(pm.state_dict()[k], pe[k]) for k in pe)
+
+
+def test_point_mae_with_256_groups_runs_fused_and_matches_per_op():
+    """cfgs/config_3.yaml (num_group 256, group_size 8; SURVEY 5 "scaling"): the decoder sees 256 tokens, more than the one-workgroup
+    attention kernel holds -- the fused stack routes T > 128 to the flash-style kernel.  Point_MAE loss and parameter gradients of
+    the fused path against the per-op path (PyTorch modules + ops.attention) on the same weights and mask, fp32."""
+    import numpy as np
+    from gm3d_amd import models_mae_learn_loss as MM
+    from gm3d_amd.point_mae import Point_MAE
+    cfg = {"group_size": 8, "num_group": 256, "loss": "cdl2",
+           "transformer_config": {"mask_ratio": 0.6, "mask_type": "rand", "trans_dim": 384, "encoder_dims": 384, "depth": 2,
+                                  "drop_path_rate": 0.0, "num_heads": 6, "decoder_depth": 2, "decoder_num_heads": 6}}
+    pts = clouds.gaussian(4, 1024, seed=77).cuda()
+    res = {}
+    was = (MM.FUSED_STACK, MM.FUSED_EMBED, MM.FUSED_HEADS)
+    try:
+        for fused in (True, False):
+            MM.FUSED_STACK = MM.FUSED_EMBED = MM.FUSED_HEADS = fused
+            torch.manual_seed(3)
+            m = Point_MAE(cfg).cuda().train()
+            np.random.seed(11)                         # the reference's host-side mask shuffle (P/models/Point_MAE.py:296-317)
+            loss = m(pts)
+            loss.backward()
+            res[fused] = (float(loss), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    finally:
+        MM.FUSED_STACK, MM.FUSED_EMBED, MM.FUSED_HEADS = was
+    assert res[True][0] == res[True][0] and abs(res[True][0] - res[False][0]) <= 1e-5 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert set(res[True][1]) == set(res[False][1])
+    gs = max(float(v.abs().max()) for v in res[False][1].values())
+    for k, v in res[False][1].items():
+        # the K=3 conv and the BatchNorm behind it: a small difference of large sums over 8192 rows (the fused node sums in fp64,
+        # the module in fp32): 3e-4, as in tests/test_gpu_embed.py; everything else 5e-5
+        tol = 3e-4 if "encoder.first_conv" in k else 5e-5
+        assert float((res[True][1][k] - v).abs().max()) <= tol * max(float(v.abs().max()), 1e-3 * gs), k
