@@ -71,6 +71,8 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_lna": [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tile_rows": [_i],
     "gm3d_gemm_tn_bf16_ring": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_ring_set_depth": [_i, _i],
+    "gm3d_gemm_tn_bf16_ring96": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -97,6 +99,7 @@ SIGNATURES = {
     "gm3d_colsum_finish_f64": [_vp, _i, _i, _i, _vp, _vp],
     "gm3d_colsum_partial": [_vp, _i, _i, _vp, _i, _vp],
     "gm3d_colsum_partial_w": [_vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_gemm_tn_bf16_dma_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dmaw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
 }
 

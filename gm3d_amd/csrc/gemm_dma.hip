@@ -45,12 +45,16 @@ __device__ __forceinline__ void dma_glds16(const void* gsrc, unsigned dst) {
 //               G = GELU(bf16(A.W^T) + bias)                                   (as gm3d_gemm_tn_bf16_gelu)
 //      2  fc2 input gradient: C = bf16(A.W^T) * GELU'(Fpre + bias), colpart[tile_m][n] = the tile's column sums of the fp32
 //               products (the fc1 bias gradient, finished later)                  (as gm3d_gemm_tn_bf16_gelu_bwd)
+//      3  mini-PointNet Conv1d(k=1) + max over each group's 32 rows (+ argmax): G (= P) [group][n] = max_k bf16(A.W^T (+ bias)),
+//               ARG the winning row (first maximum), bias before or after the pool; C (optional) = the rows
+//               (as gm3d_gemm_tn_bf16_pool: same roundings, same decisions)
 template <int WMI, int EPI, int NJ>
 __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                              const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
                                                              int lda, int ldw, int ldc, int tiles_n, int total_tiles,
                                                              bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ Fpre,
-                                                             int ldfp, float* __restrict__ colpart) {
+                                                             int ldfp, float* __restrict__ colpart, uint8_t* __restrict__ ARG,
+                                                             int bias_after_pool) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsm[];
     constexpr int BM = 64 * WMI, DBN = 64 * NJ;
     constexpr int STAGE = (BM + DBN) * 128;                 // bytes
@@ -128,7 +132,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-                if (EPI == 0 && bias) {
+                if ((EPI == 0 || (EPI == 3 && !bias_after_pool)) && bias) {
                     const float4 b = *reinterpret_cast<const float4*>(bias + n0 + col + 8 * q + 4 * hh);
                     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
                 }
@@ -139,6 +143,44 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
             }
         }
     __syncthreads();
+    if (EPI == 3) {
+        // the tile holds BM / 32 whole groups; one thread = 8 columns of one group: 32 16-byte reads down the rows of the image,
+        // values compared as the bf16 numbers they are stored as (first maximum wins: the decision of GEMM -> gm3d_group_max_fwd)
+        constexpr int CH = DBN / 8;
+        if (tid < (BM / 32) * CH) {
+            const int g = tid / CH, chunk = tid - g * CH;
+            if (m0 + 32 * g < M) {
+                const unsigned char* img = dsm + (chunk >> 3) * (BM * 128);
+                float best[8];
+                int bk[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; bk[e] = 0; }
+#pragma unroll 8
+                for (int k = 0; k < 32; ++k) {
+                    const dbf16x8 f = *reinterpret_cast<const dbf16x8*>(img + dma_off(32 * g + k, chunk & 7));
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float v = (float)f[e];
+                        if (v > best[e]) { best[e] = v; bk[e] = k; }
+                    }
+                }
+                const int n = n0 + 8 * chunk;
+                if (bias_after_pool && bias) {
+                    float bv[8];
+                    V8<float>::load(bias + n, bv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) best[e] += bv[e];
+                }
+                const size_t o = (size_t)((m0 + 32 * g) >> 5) * ldg + n;
+                V8<bf16_t>::store(G + o, best);
+                unsigned long long pk = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pk |= (unsigned long long)(bk[e] & 0xff) << (8 * e);
+                *reinterpret_cast<unsigned long long*>(ARG + o) = pk;
+            }
+        }
+        if (!C) return;
+    }
     // thread -> chunk ch = tid & 7 of rows (tid >> 3) + 32 k of image t: i = 2 WMI t + k
     float csum[NJ][8];
 #pragma unroll
@@ -152,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
         if (m0 + row < M) {
             const uint4 raw = *reinterpret_cast<const uint4*>(dsm + t * (BM * 128) + dma_off(row, ch));
             const int n = n0 + 64 * t + 8 * ch;
-            if (EPI == 0) {
+            if (EPI == 0 || EPI == 3) {
                 *reinterpret_cast<uint4*>(C + (size_t)(m0 + row) * ldc + n) = raw;
             } else {
                 const dbf16x8 f = *reinterpret_cast<const dbf16x8*>(&raw);
@@ -197,13 +239,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_dma_kernel(const bf16_t* __res
 
 static int dma_launch(const void* A, const void* W, const float* bias, void* C, void* G, int M, int N, int K, int lda, int ldw, int ldc,
                       int ldg, int bm, gm3d_stream_t stream, const void* Fpre = nullptr, int ldfp = 0, float* colpart = nullptr,
-                      int bn = 192) {
+                      int bn = 192, uint8_t* ARG = nullptr, int bias_after_pool = 0) {
     using namespace gm3d;
     if (!A || !W || (!C && !G) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
-    if ((G || Fpre) && !bias) return GM3D_EINVAL;
+    if ((G || Fpre) && !bias && !ARG) return GM3D_EINVAL;
+    if (ARG && (!G || Fpre || M % 32 || ldg % 8 || ((size_t)ARG & 7) || (bn != 128 && bn != 192))) return GM3D_EINVAL;
     if (Fpre && (!C || !colpart || G || ldfp % 8 || ldfp < N || ((size_t)Fpre & 15))) return GM3D_EINVAL;
     if (bn != 128 && bn != 192 && bn != 256) return GM3D_EUNSUPPORTED;
-    if ((G || Fpre) && bn != 192) return GM3D_EUNSUPPORTED;          // the GELU epilogues exist for the 192-column tile only
+    if ((G || Fpre) && !ARG && bn != 192) return GM3D_EUNSUPPORTED;  // the GELU epilogues exist for the 192-column tile only
     if (N % bn || K % DBK || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N)))
         return GM3D_EUNSUPPORTED;
     if ((((size_t)A | (size_t)W | (size_t)C | (size_t)G) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
@@ -218,9 +261,15 @@ static int dma_launch(const void* A, const void* W, const float* bias, void* C, 
         if (!attr.ensure((const void*)gemm_tn_dma_kernel<WMI, EPI, NJ>, lds)) return GM3D_ELAUNCH;                       \
         hipLaunchKernelGGL((gemm_tn_dma_kernel<WMI, EPI, NJ>), dim3(grid), dim3(256), lds, (hipStream_t)stream,          \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, \
-                           (bf16_t*)G, ldg, (const bf16_t*)Fpre, ldfp, colpart);                                         \
+                           (bf16_t*)G, ldg, (const bf16_t*)Fpre, ldfp, colpart, ARG, bias_after_pool);                   \
     }
-    if (Fpre) {
+    if (ARG) {
+        if (bn == 128) {
+            if (bm == 64) GM3D_DMA_LAUNCH(1, 3, 2) else GM3D_DMA_LAUNCH(2, 3, 2)
+        } else {
+            if (bm == 64) GM3D_DMA_LAUNCH(1, 3, 3) else GM3D_DMA_LAUNCH(2, 3, 3)
+        }
+    } else if (Fpre) {
         if (bm == 64) GM3D_DMA_LAUNCH(1, 2, 3) else GM3D_DMA_LAUNCH(2, 2, 3)
     } else if (G) {
         if (bm == 64) GM3D_DMA_LAUNCH(1, 1, 3) else GM3D_DMA_LAUNCH(2, 1, 3)
@@ -246,6 +295,13 @@ extern "C" int gm3d_gemm_tn_bf16_dmaw(const void* A, const void* W, const float*
                                       int ldc, int bm, int bn, gm3d_stream_t stream) {
     if (!C) return GM3D_EINVAL;
     return dma_launch(A, W, bias, C, nullptr, M, N, K, lda, ldw, ldc, 0, bm, stream, nullptr, 0, nullptr, bn);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_dma_pool(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* arg, int M, int N,
+                                          int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, int bm, int bn,
+                                          gm3d_stream_t stream) {
+    if (!P || !arg) return GM3D_EINVAL;
+    return dma_launch(A, W, bias, C, P, M, N, K, lda, ldw, ldc, ldp, bm, stream, nullptr, 0, nullptr, bn, arg, bias_after_pool);
 }
 
 extern "C" int gm3d_gemm_tn_bf16_dma_gelu(const void* A, const void* W, const float* bias, void* F, void* G, int M, int N, int K,

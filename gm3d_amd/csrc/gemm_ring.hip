@@ -37,7 +37,10 @@ __device__ __forceinline__ void ring_glds16(const void* gsrc, unsigned dst) {
 //   computes before it normalises --, a bf16 copy U16 of it (the consumer's A operand) and, per row and 128-column tile, the (mean, sum of squared deviations) of those 128
 //   values: stats[tile_n][row][2].  The LayerNorm itself is applied by the consumer GEMM while it stages its A operand
 //   (gm3d_gemm_tn_bf16_lna), so the normalised rows never make an HBM round trip of their own.
-template <int WMI, bool RES>
+// DEPTH: K-stages requested ahead of the one being multiplied (ring of DEPTH + 2 slots).  What bounds this kernel is the bytes a CU
+// has in flight towards L2 (about 1 us of loaded latency: 48 KB in flight = 50 GB/s per CU at DEPTH 2), so deeper is faster until
+// the ring no longer fits: DEPTH 4 (144 KB) for 64-row tiles, DEPTH 3 (160 KB) for 128-row tiles.
+template <int WMI, bool RES, int DEPTH>
 __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                            const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
                                                            int lda, int ldw, int ldc, int tiles_n, int total_tiles,
@@ -74,9 +77,10 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
             src[i] = W + (size_t)wn_ * ldw + ((pslot ^ ring_f(row)) << 3);
         }
     }
+    constexpr int NBUF = DEPTH + 2;
 #define GM3D_RING_STAGE(ST)                                                                          \
     {                                                                                                \
-        const unsigned base = lds0 + ((ST) % RNBUF) * STAGE;                                         \
+        const unsigned base = lds0 + ((ST) % NBUF) * STAGE;                                          \
         _Pragma("unroll") for (int i = 0; i < PIECES; ++i)                                           \
             ring_glds16(src[i] + (size_t)(ST) * RBK, base + 1024 * (w + 4 * i));                     \
     }
@@ -90,19 +94,23 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
     const int KT = K / RBK;
-    GM3D_RING_STAGE(0)
-    if (KT > 1) GM3D_RING_STAGE(1)
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d)
+        if (d < KT) GM3D_RING_STAGE(d)
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 2 < KT) {
-            GM3D_RING_STAGE(kt + 2)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-        } else if (kt + 1 < KT) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        // counted waits: stage kt has landed when at most (stages issued after it) * PIECES loads of this wave are outstanding
+        if (kt + DEPTH < KT) {
+            GM3D_RING_STAGE(kt + DEPTH)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(DEPTH * PIECES) : "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int rem = KT - 1 - kt;
+            if (DEPTH > 3 && rem == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PIECES) : "memory");
+            else if (DEPTH > 2 && rem == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
+            else if (rem == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
-        const unsigned char* as = rsm + (kt % RNBUF) * STAGE;
+        const unsigned char* as = rsm + (kt % NBUF) * STAGE;
         const unsigned char* ws = as + BM * 128;
         rbf16x8 fa[4][WMI], fw[4][2];
 #pragma unroll
@@ -199,7 +207,131 @@ __global__ __launch_bounds__(256) void gemm_tn_ring_kernel(const bf16_t* __restr
     }
 }
 
+
+// ---- 96-column form: N = 384 as FOUR column tiles ----------------------------------------------------------------------------
+// With 128-column tiles an N = 384 product has 3 tiles per row block: 150 (3200 rows) / 192 (4096, or 8192 in 128-row tiles)
+// workgroups for 256 CUs, and what bounds each of them is the bytes its CU pulls from L2 (DESIGN 3b').  Four 96-column tiles per
+// row block give 200 / 256 / 256 workgroups that each pull (BM + 96) instead of (BM + 128) operand rows per K-step: every CU
+// busy AND 17 % (64-row) / 12.5 % (128-row) fewer bytes per workgroup, with no split-K fix-up and no cross-workgroup hand-off.
+// Three waves (192 threads), wave w owns columns 32 w .. 32 w + 31 of the tile and all its rows; the same four-stage LDS-DMA ring,
+// the same swizzled image and the same MFMA order along K as above -> results bit-identical to the 128-column kernel.
+constexpr int R96 = 96, RCP96 = 100;
+
+template <int WMI>
+__global__ __launch_bounds__(192) void gemm_tn_ring96_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                             const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N, int K,
+                                                             int lda, int ldw, int ldc, int tiles_n, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char rsm[];
+    constexpr int BM = 64 * WMI, NMT = 2 * WMI;             // 32-row MFMA tiles per wave
+    constexpr int STAGE = (BM + R96) * 128;                 // bytes
+    constexpr int PA = BM / 8, NP = PA + 12;                // 1-KiB pieces per stage: 20 / 28
+    constexpr int PMAX = (NP + 2) / 3;                      // pieces of wave 0 (7 / 10); waves 1, 2 may have one fewer
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total_tiles) return;
+    const int tile_m = logical / tiles_n, tile_n = logical - tile_m * tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * R96;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)rsm;
+    const int mine = (NP - w + 2) / 3;                      // pieces p = w + 3 i < NP
+
+    const int prow = lane >> 3, pslot = lane & 7;
+    const bf16_t* src[PMAX];
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int p = w + 3 * i < NP ? w + 3 * i : w;       // (a piece past NP is never issued; keep the pointer valid)
+        if (p < PA) {
+            const int row = 8 * p + prow;
+            const int am = m0 + row < M ? m0 + row : M - 1;
+            src[i] = A + (size_t)am * lda + ((pslot ^ ring_f(row)) << 3);
+        } else {
+            const int row = 8 * (p - PA) + prow;
+            src[i] = W + (size_t)(n0 + row) * ldw + ((pslot ^ ring_f(row)) << 3);
+        }
+    }
+#define GM3D_R96_STAGE(ST)                                                                           \
+    {                                                                                                \
+        const unsigned base = lds0 + ((ST) % RNBUF) * STAGE;                                         \
+        _Pragma("unroll") for (int i = 0; i < PMAX; ++i)                                             \
+            if (i < mine) ring_glds16(src[i] + (size_t)(ST) * RBK, base + 1024 * (w + 3 * i));       \
+    }
+    rf32x16 acc[NMT];
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[i][g] = 0.f;
+
+    const int KT = K / RBK;
+    GM3D_R96_STAGE(0)
+    if (KT > 1) GM3D_R96_STAGE(1)
+    for (int kt = 0; kt < KT; ++kt) {
+        // counted waits: this wave has `mine` loads per stage in flight (PMAX or PMAX - 1; uniform per wave)
+        if (kt + 2 < KT) {
+            GM3D_R96_STAGE(kt + 2)
+            if (mine == PMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PMAX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PMAX - 1)) : "memory");
+        } else if (kt + 1 < KT) {
+            if (mine == PMAX) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMAX) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PMAX - 1) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        const unsigned char* as = rsm + (kt % RNBUF) * STAGE;
+        const unsigned char* ws = as + BM * 128;
+        rbf16x8 fa[4][NMT], fw[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) fa[s][i] = *reinterpret_cast<const rbf16x8*>(as + ring_off(32 * i + r, 2 * s + hh));
+            fw[s] = *reinterpret_cast<const rbf16x8*>(ws + ring_off(32 * w + r, 2 * s + hh));
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < NMT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[s], fa[s][i], acc[i], 0, 0, 0);
+    }
+#undef GM3D_R96_STAGE
+    __syncthreads();
+    float* cs = reinterpret_cast<float*>(rsm);              // [BM][RCP96] fp32 staging tile (25 / 50 KiB of the ring)
+#pragma unroll
+    for (int i = 0; i < NMT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int m = 32 * i + r, n = 32 * w + 8 * q + 4 * hh;
+            *reinterpret_cast<float4*>(cs + m * RCP96 + n) = make_float4(acc[i][4 * q], acc[i][4 * q + 1], acc[i][4 * q + 2], acc[i][4 * q + 3]);
+        }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < BM * 12 / 192; ++i) {                // 12 chunks of 8 columns per row
+        const int c = tid + 192 * i;
+        const int row = c / 12, nc = (c - row * 12) * 8;
+        if (m0 + row < M) {
+            float v[8];
+            const float4 x = *reinterpret_cast<const float4*>(cs + row * RCP96 + nc), y = *reinterpret_cast<const float4*>(cs + row * RCP96 + nc + 4);
+            v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
+            if (bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(bias + n0 + nc), b1 = *reinterpret_cast<const float4*>(bias + n0 + nc + 4);
+                v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+            }
+            V8<bf16_t>::store(C + (size_t)(m0 + row) * ldc + n0 + nc, v);
+        }
+    }
+}
+
 }  // namespace gm3d
+
+// K-stages in flight ahead of the multiplied one, per tile height (64, 128); gm3d_gemm_ring_set_depth is the measurement knob of
+// tools/gemm_kbench.py (values outside the supported range are clamped)
+static int RING_DEPTH[2] = {2, 2};
+
+extern "C" int gm3d_gemm_ring_set_depth(int bm, int depth) {
+    if (bm != 64 && bm != 128) return GM3D_EINVAL;
+    const int hi = bm == 64 ? 4 : 3;
+    RING_DEPTH[bm == 64 ? 0 : 1] = depth < 2 ? 2 : (depth > hi ? hi : depth);
+    return GM3D_OK;
+}
 
 static int ring_launch(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw, int ldc, int bm,
                        gm3d_stream_t stream, const float* res, const float* rowscale, int rows_per_sample, const void* add, float* U,
@@ -215,19 +347,22 @@ static int ring_launch(const void* A, const void* W, const float* bias, void* C,
     const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + RBN - 1) / RBN;
     if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
-    const size_t lds = (size_t)RNBUF * (bm + RBN) * 128;
-#define GM3D_RING_LAUNCH(WMI, RES)                                                                                        \
+    const int depth = U ? 2 : RING_DEPTH[bm == 64 ? 0 : 1];
+    const size_t lds = (size_t)(depth + 2) * (bm + RBN) * 128;
+#define GM3D_RING_LAUNCH(WMI, RES, DEPTH)                                                                                 \
     {                                                                                                                    \
-        static LdsAttr attr;                                                                                            \
-        if (!attr.ensure((const void*)gemm_tn_ring_kernel<WMI, RES>, lds)) return GM3D_ELAUNCH;                         \
-        hipLaunchKernelGGL((gemm_tn_ring_kernel<WMI, RES>), dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)A, \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, res, rowscale,    \
-                           rows_per_sample, (const bf16_t*)add, U, stats, (bf16_t*)U16);                                 \
+        static LdsAttr attr;                                                                                             \
+        if (!attr.ensure((const void*)gemm_tn_ring_kernel<WMI, RES, DEPTH>, lds)) return GM3D_ELAUNCH;                   \
+        hipLaunchKernelGGL((gemm_tn_ring_kernel<WMI, RES, DEPTH>), dim3(grid), dim3(256), lds, (hipStream_t)stream,      \
+                           (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total, \
+                           res, rowscale, rows_per_sample, (const bf16_t*)add, U, stats, (bf16_t*)U16);                  \
     }
     if (U) {
-        if (bm == 64) GM3D_RING_LAUNCH(1, true) else GM3D_RING_LAUNCH(2, true)
+        if (bm == 64) GM3D_RING_LAUNCH(1, true, 2) else GM3D_RING_LAUNCH(2, true, 2)
+    } else if (bm == 64) {
+        if (depth == 2) GM3D_RING_LAUNCH(1, false, 2) else if (depth == 3) GM3D_RING_LAUNCH(1, false, 3) else GM3D_RING_LAUNCH(1, false, 4)
     } else {
-        if (bm == 64) GM3D_RING_LAUNCH(1, false) else GM3D_RING_LAUNCH(2, false)
+        if (depth == 2) GM3D_RING_LAUNCH(2, false, 2) else GM3D_RING_LAUNCH(2, false, 3)
     }
 #undef GM3D_RING_LAUNCH
     GM3D_CHECK_LAUNCH();
@@ -238,6 +373,32 @@ extern "C" int gm3d_gemm_tn_bf16_ring(const void* A, const void* W, const float*
                                       int ldc, int bm, gm3d_stream_t stream) {
     if (!C) return GM3D_EINVAL;
     return ring_launch(A, W, bias, C, M, N, K, lda, ldw, ldc, bm, stream, nullptr, nullptr, 1, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_ring96(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                                        int ldc, int bm, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!A || !W || !C || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (N % R96 || K % RBK || lda % 8 || ldw % 8 || lda < K || ldw < K || ldc % 8 || ldc < N) return GM3D_EUNSUPPORTED;
+    if ((((size_t)A | (size_t)W | (size_t)C) & 15) || (bm != 64 && bm != 128)) return GM3D_EUNSUPPORTED;
+    if (M == 0) return GM3D_OK;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / R96;
+    if ((long long)tiles_m * tiles_n > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    const int total = tiles_m * tiles_n, grid = (total + 7) / 8 * 8;
+    const size_t lds = (size_t)RNBUF * (bm + R96) * 128;
+    if (bm == 64) {
+        static LdsAttr attr;
+        if (!attr.ensure((const void*)gemm_tn_ring96_kernel<1>, lds)) return GM3D_ELAUNCH;
+        hipLaunchKernelGGL((gemm_tn_ring96_kernel<1>), dim3(grid), dim3(192), lds, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)W,
+                           bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total);
+    } else {
+        static LdsAttr attr;
+        if (!attr.ensure((const void*)gemm_tn_ring96_kernel<2>, lds)) return GM3D_ELAUNCH;
+        hipLaunchKernelGGL((gemm_tn_ring96_kernel<2>), dim3(grid), dim3(192), lds, (hipStream_t)stream, (const bf16_t*)A, (const bf16_t*)W,
+                           bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total);
+    }
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
 }
 
 extern "C" int gm3d_gemm_tn_bf16_res(const void* A, const void* W, const float* bias, const float* res, const float* rowscale,

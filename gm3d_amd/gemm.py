@@ -46,6 +46,17 @@ def linear_tn_ring(x, w, bias=None, out=None, bm=None):
     return out
 
 
+def linear_tn_ring96(x, w, bias=None, out=None, bm=64):
+    """linear_tn through the ring kernel with 96-column tiles (N % 96 == 0; csrc/gemm_ring.hip): bit-identical."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_ring96", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ring96, _ptr(x), _ptr(w), _ptr(bias), _ptr(out),
+            M, N, K, x.stride(0), w.stride(0), out.stride(0), int(bm), _stream())
+    return out
+
+
 USE_DMA = True            # K = 384 products over >= 6 column tiles of 192 on csrc/gemm_dma.hip (qkv, fc1 + GELU, fc2 input gradient)
 
 
@@ -162,10 +173,11 @@ def choose(M, N, K):
     Round 3: NO shape goes to the library any more (round 2 kept a shape there where the tuned hipBLASLt solution was >= 5 %
     faster): every product of the bf16 step is one of our kernels with a fixed accumulation order -- eager == captured by
     construction, and the measured path no longer depends on a TunableOp table."""
-    if (N, K) == (384, 384):
-        return "ring64" if M <= 4096 else "ring128"
-    if N == 384 and K in (1024, 1152, 1536):            # long K, three column tiles: the ring's regime
-        return "ring64" if M <= 4096 else "ring128"
+    if N == 384 and K in (384, 1024, 1152, 1536):       # three column tiles: 150 .. 192 workgroups for 256 CUs
+        # <= 4096 rows: the ring (64-row tiles, one workgroup per CU, two K-stages in flight); above: two workgroups per CU on
+        # 64 x 128 double-buffer tiles, 2-8 % ahead of the 128-row ring.  Neither 96-column tiles (every CU busy, fewer bytes per
+        # workgroup) nor a deeper ring helps: the r03 table has both slower -- the chip-wide L2 -> LDS rate is what is exhausted
+        return "ring64" if M <= 4096 else "dma64x128"
     if (N, K) == (1152, 384):
         return "ring128" if M <= 3200 else ("dma64x192" if M <= 4096 else "dma128x192") if USE_DMA else "own"
     if K == 384 and N % 192 == 0 and N > 384 and M < 32768:
@@ -222,6 +234,9 @@ def mm_nn(x, w, out=None):
     return y if out is None else out.copy_(y)
 
 
+POOL_ON_DMA = True        # the pool epilogue on csrc/gemm_dma.hip (128 x 128 / 128 x 192 tiles) instead of csrc/gemm.hip
+
+
 def linear_pool(x, w, bias, bias_after_pool, want_rows):
     """Conv1d(k=1) over (groups*32, K) rows + max over each group's 32 rows in the GEMM epilogue.
     -> (rows (M,N) bf16 | None, pooled (M/32,N) bf16, argmax (M/32,N) uint8)."""
@@ -230,6 +245,11 @@ def linear_pool(x, w, bias, bias_after_pool, want_rows):
     rows = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_rows else None
     pooled = torch.empty(M // 32, N, dtype=torch.bfloat16, device=x.device)
     arg = torch.empty(M // 32, N, dtype=torch.uint8, device=x.device)
+    if POOL_ON_DMA and N % 8 == 0 and (N % 192 == 0 or N % 128 == 0):
+        bn = 192 if N % 192 == 0 else 128
+        _launch("gm3d_gemm_tn_bf16_dma_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dma_pool, _ptr(x), _ptr(w), _ptr(bias),
+                _ptr(rows), _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), 128, bn, _stream())
+        return rows, pooled, arg
     _launch("gm3d_gemm_tn_bf16_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
             _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), _stream())
     return rows, pooled, arg

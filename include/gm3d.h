@@ -384,6 +384,14 @@ int gm3d_gemm_tile_rows(int M);
  * last column tile: the 96-wide reconstruction head increase_dim_just_network_without_feature, models_mae_learn_loss.py:169-176). */
 int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
                            int bm, gm3d_stream_t stream);
+/* Ring depth of gm3d_gemm_tn_bf16_ring: K-stages requested ahead of the one being multiplied (2 .. 4 for bm = 64, 2 .. 3 for
+ * bm = 128; clamped).  Results do not depend on it.  Process-wide; set before capturing a graph. */
+int gm3d_gemm_ring_set_depth(int bm, int depth);
+/* The ring kernel with 96-column tiles (N % 96 == 0): N = 384 -- attn.proj, mlp.fc2 and the input gradients of fc1 / qkv / proj of
+ * the timm Block (Point-MAE_SA3D/models/Point_MAE.py:82-125) -- as four column tiles per row block instead of three: 200 / 256
+ * workgroups instead of 150 / 192 for 256 CUs, each pulling fewer operand bytes from L2.  Bit-identical results.  bm = 64 or 128. */
+int gm3d_gemm_tn_bf16_ring96(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
+                             int bm, gm3d_stream_t stream);
 /* The same products for SHORT K over many tiles (csrc/gemm_dma.hip: 64- or 128-row x 192-column tiles, LDS-DMA double buffer, two
  * workgroups per CU): qkv, fc1, proj, the proj / fc2 input gradients (K = 384).  N % 192 == 0, K % 64 == 0, 16-byte aligned
  * operands; results bit-identical to gm3d_gemm_tn_bf16 / gm3d_gemm_tn_bf16_ring.  bm = 64 or 128. */
@@ -395,6 +403,10 @@ int gm3d_gemm_tn_bf16_dma(const void *A, const void *W, const float *bias, void 
  * first_conv.3's input gradient (256 -> 128, :876) and pos_embed.2's (384 -> 128, :104-108).  Bit-identical to the other forms. */
 int gm3d_gemm_tn_bf16_dmaw(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
                            int bm, int bn, gm3d_stream_t stream);
+/* ... with the max-pool epilogue of gm3d_gemm_tn_bf16_pool (mini-PointNet Conv1d(k=1) + max over each group's 32 points,
+ * models_mae_learn_loss.py:893,897): same roundings and decisions, bm x bn tiles with bn = 128 or 192. */
+int gm3d_gemm_tn_bf16_dma_pool(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N,
+                               int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, int bm, int bn, gm3d_stream_t stream);
 /* ... with the fc1 epilogue of gm3d_gemm_tn_bf16_gelu: F (optional) = bf16(A.W^T), G = GELU(F + bias). */
 int gm3d_gemm_tn_bf16_dma_gelu(const void *A, const void *W, const float *bias, void *F, void *G, int M, int N, int K, int lda,
                                int ldw, int ldf, int ldg, int bm, gm3d_stream_t stream);

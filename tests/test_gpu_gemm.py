@@ -65,11 +65,14 @@ def test_gemm_gelu_epilogue(M, with_f):
 
 @pytest.mark.parametrize("groups,K,N,after,rows", [(8192, 128, 256, False, True), (8192, 512, 384, True, False), (37, 128, 256, False, True),
                                                    (5, 512, 384, True, False)])
-def test_gemm_pool_epilogue(groups, K, N, after, rows):
-    """conv + max over the 32 rows of each group in the GEMM epilogue == the same GEMM followed by gm3d_group_max_fwd."""
+@pytest.mark.parametrize("on_dma", [True, False])
+def test_gemm_pool_epilogue(groups, K, N, after, rows, on_dma, monkeypatch):
+    """conv + max over the 32 rows of each group in the GEMM epilogue == the same GEMM followed by gm3d_group_max_fwd; on both
+    kernels that carry the epilogue (csrc/gemm_dma.hip: the default since round 3; csrc/gemm.hip)."""
     from gm3d_amd import gemm
     from gm3d_amd._capi import lib, check
     from gm3d_amd.ops import _ptr, _stream
+    monkeypatch.setattr(gemm, "POOL_ON_DMA", on_dma)
     M = groups * 32
     g = torch.Generator(device="cuda").manual_seed(groups + K)
     x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
@@ -295,3 +298,21 @@ def test_gemm_mm_nn_equals_transposed_product():
         assert torch.equal(got, gemm.mm(x, w.t().contiguous()))
         ref = x.float() @ w.float()
         assert float((got.float() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()) + 1e-2
+
+
+@pytest.mark.parametrize("M,K,N", [(4096, 1536, 384), (3200, 384, 384), (8192, 1152, 384), (200, 64, 96), (333, 1536, 192), (3200, 128, 1152)])
+@pytest.mark.parametrize("bm", [64, 128])
+def test_gemm_ring96_equals_ring(M, K, N, bm):
+    """The 96-column form of the ring kernel (N = 384 as four column tiles: every CU gets a tile) accumulates along K in the same
+    order as the 128-column form: bit-identical results, with and without bias, rows past M untouched."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N + bm)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias in (None, b):
+        want = gemm.linear_tn_ring(x, w, bias, bm=64)
+        out = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn_ring96(x, w, bias, out=out[:M], bm=bm)
+        assert torch.equal(out[:M], want)
+        assert bool((out[M:] == 7.0).all())

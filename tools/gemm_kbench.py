@@ -37,6 +37,8 @@ def train(fn, sets, iters=40):
 if __name__ == "__main__":
     import sys
     only_new = "--new" in sys.argv
+    if "--n384" in sys.argv:
+        SHAPES[:] = [(M, K, 384) for M in (3200, 4096, 8192) for K in (384, 1152, 1536)]
     for M, K, N in SHAPES:
         if only_new and M in (4096, 3200) or (only_new and M == 8192 and (K, N) in ((384, 1152), (384, 384), (384, 1536), (1536, 384), (1152, 384))):
             continue
@@ -48,7 +50,12 @@ if __name__ == "__main__":
         if K // 64 in gemm.OWN_KT:
             res["own"] = train(lambda x, w, o: gemm.linear_tn(x, w, out=o), sets)
         for bm in (64, 128):
-            res["ring%d" % bm] = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=bm), sets)
+            for depth in ((2, 3, 4) if bm == 64 else (2, 3)):
+                gemm.lib.gm3d_gemm_ring_set_depth(bm, depth)
+                res["ring%d%s" % (bm, "" if depth == 2 else "d%d" % depth)] = train(lambda x, w, o: gemm.linear_tn_ring(x, w, out=o, bm=bm), sets)
+            gemm.lib.gm3d_gemm_ring_set_depth(bm, 2)
+            if N % 96 == 0:
+                res["r96_%d" % bm] = train(lambda x, w, o: gemm.linear_tn_ring96(x, w, out=o, bm=bm), sets)
             for bn in (128, 192, 256):
                 if N % bn == 0:
                     res["dma%dx%d" % (bm, bn)] = train(lambda x, w, o: gemm.linear_tn_dmaw(x, w, out=o, bm=bm, bn=bn), sets)
