@@ -163,6 +163,9 @@ def linear_tn_dmaw(x, w, bias=None, out=None, bm=128, bn=256):
     return out
 
 
+N384_BIG = "ring128"      # N = 384 above 4096 rows.  "dma64x128" (two workgroups per CU) is 2-8 % faster launch by launch
+#                           (profiles/r03_gemm_kbench.txt) and 1.1 % SLOWER in the step (same-box A/B, gpurun_out/r3i: 8.08 vs 7.99 ms):
+#                           these launches run beside the other decoder's chain, which the second workgroup per CU displaces
 OWN_KT = (2, 4, 6, 8, 16, 18, 24)      # K / 64 values csrc/gemm.hip is unrolled for
 
 
@@ -174,10 +177,9 @@ def choose(M, N, K):
     faster): every product of the bf16 step is one of our kernels with a fixed accumulation order -- eager == captured by
     construction, and the measured path no longer depends on a TunableOp table."""
     if N == 384 and K in (384, 1024, 1152, 1536):       # three column tiles: 150 .. 192 workgroups for 256 CUs
-        # <= 4096 rows: the ring (64-row tiles, one workgroup per CU, two K-stages in flight); above: two workgroups per CU on
-        # 64 x 128 double-buffer tiles, 2-8 % ahead of the 128-row ring.  Neither 96-column tiles (every CU busy, fewer bytes per
+        # the ring, one workgroup per CU, two K-stages in flight.  Neither 96-column tiles (every CU busy, fewer bytes per
         # workgroup) nor a deeper ring helps: the r03 table has both slower -- the chip-wide L2 -> LDS rate is what is exhausted
-        return "ring64" if M <= 4096 else "dma64x128"
+        return "ring64" if M <= 4096 else N384_BIG
     if (N, K) == (1152, 384):
         return "ring128" if M <= 3200 else ("dma64x192" if M <= 4096 else "dma128x192") if USE_DMA else "own"
     if K == 384 and N % 192 == 0 and N > 384 and M < 32768:
