@@ -5,7 +5,7 @@ mkdir -p $out
 for rep in 1 2; do
   for spec in "$@"; do
     label=${spec%%:*}; sw=${spec#*:}
-    python tools/bench_with.py $sw -- --steps 40 --warmup 10 --no-cpu-baseline > $out/ab_${label}_$rep.json 2> $out/ab_${label}_$rep.err
+    python tools/bench_with.py $sw -- --steps 40 --warmup 10 --no-cpu-baseline --no-secondary > $out/ab_${label}_$rep.json 2> $out/ab_${label}_$rep.err
     python - <<PY
 import json
 d=json.loads(open("$out/ab_${label}_$rep.json").read().strip().splitlines()[-1])
