@@ -152,7 +152,12 @@ __global__ __launch_bounds__(256) void residual_ln_fwd_kernel(const float* __res
 template <class T, int NQ>
 __global__ __launch_bounds__(256) void ln_plain_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, T* __restrict__ h,
-                                                           float* __restrict__ mean, float* __restrict__ rstd, int R, int C) {
+                                                           float* __restrict__ mean, float* __restrict__ rstd, int R, int C,
+                                                           const T* __restrict__ y, const float* __restrict__ ybias,
+                                                           const float* __restrict__ rowscale, int rows_per_sample,
+                                                           const T* __restrict__ z, T* __restrict__ s_out) {
+    // optional residual form (the hierarchical encoder's blocks, any width): s = x + rowscale[sample] * (y + ybias) + z is formed
+    // here, stored once in T (s_out) and normalised AS STORED (so the backward, which re-reads s, sees the same xhat)
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
     const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     const int stride = gridDim.x * 8;
@@ -163,13 +168,39 @@ __global__ __launch_bounds__(256) void ln_plain_fwd_kernel(const T* __restrict__
         const size_t base = (size_t)r * C;
         float v[NQ][4];
         float s = 0.f;
+        const float rsc = (y && rowscale) ? rowscale[r / rows_per_sample] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int c = 4 * hl + 128 * i;
-            if (c < C) Quad<T>::load(x + base + c, v[i]);
-            else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+            if (c < C) {
+                Quad<T>::load(x + base + c, v[i]);
+                if (y) {
+                    float t[4];
+                    Quad<T>::load(y + base + c, t);
+                    if (ybias) {
+                        float bq[4];
+                        Quad<float>::load(ybias + c, bq);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) t[j] += bq[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] += rsc * t[j];
+                }
+                if (z) {
+                    float t[4];
+                    Quad<T>::load(z + base + c, t);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] += t[j];
+                }
+                if (s_out) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[i][j] = (float)(T)v[i][j];
+                    if (valid) Quad<T>::store(s_out + base + c, v[i]);
+                }
+            } else v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
             s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
+        if (!gamma) continue;                    // sum only (the tail of a block stack: no LayerNorm follows)
         const float mu = half_sum(s, lane) * invc;
         float q = 0.f;
 #pragma unroll
@@ -201,20 +232,25 @@ template <class T, int NQ>
 __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ x,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
                                                            const float* __restrict__ gamma, T* __restrict__ dx,
-                                                           float* __restrict__ partial, int R, int C) {
-    __shared__ float red[8][2 * 512];
+                                                           float* __restrict__ partial, int R, int C,
+                                                           const T* __restrict__ gin, const float* __restrict__ rowscale,
+                                                           int rows_per_sample, T* __restrict__ dy, int nsum) {
+    // optional residual form: dx = gin + LayerNorm-backward (the gradient of s in ln_plain_fwd_kernel's residual form: it goes to x
+    // and z as it stands), dy = rowscale[sample] * dx (the gradient of y; written only when it differs from dx), and with
+    // nsum == 3 a third column-sum block: sum_rows dy = the gradient of ybias (the bias of the Linear that produced y)
+    __shared__ float red[8][3 * 512];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, slot = (threadIdx.x >> 6) * 2 + half;
     const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     const int stride = gridDim.x * 8;
     const float invc = 1.0f / (float)C;
-    float sg[NQ][4], sb[NQ][4], gm[NQ][4];
+    float sg[NQ][4], sb[NQ][4], sy[NQ][4], gm[NQ][4];
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int c = 4 * hl + 128 * i;
         if (c < C) Quad<float>::load(gamma + c, gm[i]);
         else gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) sg[i][j] = sb[i][j] = 0.f;
+        for (int j = 0; j < 4; ++j) sg[i][j] = sb[i][j] = sy[i][j] = 0.f;
     }
     for (int rb = wbase; rb < R; rb += stride) {
         const bool valid = rb + half < R;
@@ -227,7 +263,8 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
         for (int i = 0; i < NQ; ++i) {
             const int c = 4 * hl + 128 * i;
             if (c < C) {
-                Quad<T>::load(dh + base + c, d[i]);
+                if (dh) Quad<T>::load(dh + base + c, d[i]);
+                else d[i][0] = d[i][1] = d[i][2] = d[i][3] = 0.f;       // no LayerNorm behind the sum: dx = gin
                 Quad<T>::load(x + base + c, xh[i]);
             } else {
 #pragma unroll
@@ -242,17 +279,33 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
             }
         }
         const float m1 = half_sum(a, lane) * invc, m2 = half_sum(b, lane) * invc;
+        const float rsc = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int c = 4 * hl + 128 * i;
             if (c < C) {
-                float o[4];
+                float o[4], gq[4] = {0.f, 0.f, 0.f, 0.f};
+                if (gin) Quad<T>::load(gin + base + c, gq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = rs * (d[i][j] * gm[i][j] - m1 - xh[i][j] * m2);
+                    o[j] = gq[j] + rs * (d[i][j] * gm[i][j] - m1 - xh[i][j] * m2);
                     if (valid) { sg[i][j] += d[i][j] * xh[i][j]; sb[i][j] += d[i][j]; }
                 }
                 if (valid) Quad<T>::store(dx + base + c, o);
+                if (nsum == 3) {
+                    float oy[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        oy[j] = (float)(T)(rsc * (float)(T)o[j]);          // dy as the next kernel will read it
+                        if (valid) sy[i][j] += oy[j];
+                    }
+                    if (valid && dy) Quad<T>::store(dy + base + c, oy);
+                } else if (dy && valid) {
+                    float oy[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) oy[j] = rsc * (float)(T)o[j];
+                    Quad<T>::store(dy + base + c, oy);
+                }
             }
         }
     }
@@ -262,16 +315,16 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
         const int c = 4 * hl + 128 * i;
         if (c < C) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[i][j]; red[slot][512 + c + j] = sb[i][j]; }
+            for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[i][j]; red[slot][512 + c + j] = sb[i][j]; red[slot][1024 + c + j] = sy[i][j]; }
         }
     }
     __syncthreads();
-    for (int t = threadIdx.x; t < 2 * C; t += 256) {
+    for (int t = threadIdx.x; t < nsum * C; t += 256) {
         const int which = t / C, c = t - which * C;
         float acc = 0.f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) acc += red[k][which * 512 + c];
-        partial[((size_t)blockIdx.x * 2 + which) * C + c] = acc;
+        partial[((size_t)blockIdx.x * nsum + which) * C + c] = acc;
     }
 }
 
@@ -588,17 +641,32 @@ extern "C" int gm3d_residual_ln_bwd(const void* dh, const float* gin, const floa
 
 extern "C" int gm3d_ln_plain_partial_rows(int R) { return R < 1 ? 0 : gm3d::ln_grid(R); }
 
+extern "C" int gm3d_add_ln_fwd(const void* x, const void* y, const float* ybias, const float* rowscale, int rows_per_sample, const void* z,
+                               const float* gamma, const float* beta, float eps, void* s_out, void* h, float* mean, float* rstd, int R,
+                               int C, int dtype, gm3d_stream_t stream);
+
 extern "C" int gm3d_ln_plain_fwd(const void* x, const float* gamma, const float* beta, float eps, void* h, float* mean, float* rstd,
                                  int R, int C, int dtype, gm3d_stream_t stream) {
+    return gm3d_add_ln_fwd(x, nullptr, nullptr, nullptr, 1, nullptr, gamma, beta, eps, nullptr, h, mean, rstd, R, C, dtype, stream);
+}
+
+extern "C" int gm3d_add_ln_fwd(const void* x, const void* y, const float* ybias, const float* rowscale, int rows_per_sample, const void* z,
+                               const float* gamma, const float* beta, float eps, void* s_out, void* h, float* mean, float* rstd, int R,
+                               int C, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!x || !gamma || !beta || !h || !mean || !rstd || R < 0) return GM3D_EINVAL;
+    if (!x || R < 0) return GM3D_EINVAL;
+    if (gamma ? (!beta || !h || !mean || !rstd) : (!s_out || !(y || z))) return GM3D_EINVAL;      // gamma NULL: the sum only
+    if ((ybias || rowscale) && !y) return GM3D_EINVAL;
+    if ((y || z) && !s_out) return GM3D_EINVAL;                    // the backward re-reads the sum
+    if (rowscale && rows_per_sample < 1) return GM3D_EINVAL;
     if (C < 4 || C % 4 || C > 512) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (R == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
     const int nq = (C + 127) / 128;
 #define GM3D_LNP_F(T_, NQ_) hipLaunchKernelGGL((ln_plain_fwd_kernel<T_, NQ_>), dim3(ln_fwd_grid(R)), dim3(256), 0, st, (const T_*)x, gamma, \
-                                               beta, eps, (T_*)h, mean, rstd, R, C)
+                                               beta, eps, (T_*)h, mean, rstd, R, C, (const T_*)y, ybias, rowscale, rows_per_sample,      \
+                                               (const T_*)z, (T_*)s_out)
     if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_F(bf16_t, 1); else if (nq == 2) GM3D_LNP_F(bf16_t, 2); else if (nq == 3) GM3D_LNP_F(bf16_t, 3); else GM3D_LNP_F(bf16_t, 4); }
     else { if (nq == 1) GM3D_LNP_F(float, 1); else if (nq == 2) GM3D_LNP_F(float, 2); else if (nq == 3) GM3D_LNP_F(float, 3); else GM3D_LNP_F(float, 4); }
 #undef GM3D_LNP_F
@@ -606,16 +674,28 @@ extern "C" int gm3d_ln_plain_fwd(const void* x, const float* gamma, const float*
     return GM3D_OK;
 }
 
+extern "C" int gm3d_add_ln_bwd(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, int R, int C,
+                               int dtype, gm3d_stream_t stream);
+
 extern "C" int gm3d_ln_plain_bwd(const void* dh, const void* x, const float* mean, const float* rstd, const float* gamma, void* dx,
                                  float* partial, int R, int C, int dtype, gm3d_stream_t stream) {
+    return gm3d_add_ln_bwd(dh, nullptr, x, mean, rstd, gamma, nullptr, 1, dx, nullptr, partial, 2, R, C, dtype, stream);
+}
+
+extern "C" int gm3d_add_ln_bwd(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
+                               const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, int R, int C,
+                               int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!dh || !x || !mean || !rstd || !gamma || !dx || !partial || R < 1) return GM3D_EINVAL;
+    if (!x || !mean || !rstd || !gamma || !dx || !partial || R < 1 || (!dh && !gin)) return GM3D_EINVAL;
+    if ((nsum != 2 && nsum != 3) || (rowscale && (!dy || rows_per_sample < 1))) return GM3D_EINVAL;
     if (C < 4 || C % 4 || C > 512) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const int nq = (C + 127) / 128;
 #define GM3D_LNP_B(T_, NQ_) hipLaunchKernelGGL((ln_plain_bwd_kernel<T_, NQ_>), dim3(ln_grid(R)), dim3(256), 0, st, (const T_*)dh, (const T_*)x, \
-                                               mean, rstd, gamma, (T_*)dx, partial, R, C)
+                                               mean, rstd, gamma, (T_*)dx, partial, R, C, (const T_*)gin, rowscale, rows_per_sample,     \
+                                               (T_*)dy, nsum)
     if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_B(bf16_t, 1); else if (nq == 2) GM3D_LNP_B(bf16_t, 2); else if (nq == 3) GM3D_LNP_B(bf16_t, 3); else GM3D_LNP_B(bf16_t, 4); }
     else { if (nq == 1) GM3D_LNP_B(float, 1); else if (nq == 2) GM3D_LNP_B(float, 2); else if (nq == 3) GM3D_LNP_B(float, 3); else GM3D_LNP_B(float, 4); }
 #undef GM3D_LNP_B

@@ -121,6 +121,129 @@ class LayerNormFn(torch.autograd.Function):
             return dx.view(ctx.shp).to(ctx.xdt), gb[:C].to(w.dtype), gb[C:].to(w.dtype), None, None
 
 
+class AddLayerNormFn(torch.autograd.Function):
+    """(s, h) with s = x + rowscale[sample] * (y + ybias) + z and h = LayerNorm(s): the residual sum(s) in front of a pre-norm block's
+    LayerNorm formed inside the LayerNorm kernel (csrc/rowops.hip gm3d_add_ln_fwd/bwd; any width <= 512).  y, ybias, rowscale, z
+    optional.  Backward: ONE launch gives the gradient of s (= of x and z), of y (scaled), LayerNorm's gamma / beta sums and the
+    column sum that is ybias's gradient (the bias of the Linear that produced y is added here, so that Linear runs without one)."""
+
+    @staticmethod
+    def forward(ctx, x, y, ybias, rowscale, z, w, b, eps, adt):
+        with torch.autocast("cuda", enabled=False):
+            C = x.shape[-1]
+            x2 = x.reshape(-1, C).to(adt).contiguous()
+            R = x2.shape[0]
+            y2 = y.reshape(R, C).to(adt).contiguous() if y is not None else None
+            z2 = z.reshape(R, C).to(adt).contiguous() if z is not None else None
+            rps = R // rowscale.shape[0] if rowscale is not None else 1
+            h = torch.empty_like(x2)
+            s = torch.empty_like(x2) if (y2 is not None or z2 is not None) else None
+            mean = torch.empty(R, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(R, dtype=torch.float32, device=x.device)
+            yb = _c32(ybias) if ybias is not None else None
+            _launch("gm3d_add_ln_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_fwd, _ptr(x2), _ptr(y2), _ptr(yb), _ptr(rowscale),
+                    int(rps), _ptr(z2), _ptr(_c32(w)), _ptr(_c32(b)), float(eps), _ptr(s), _ptr(h), _ptr(mean), _ptr(rstd), R, C, _DT[adt],
+                    _stream())
+            if s is None:        # plain LayerNorm: the "sum" is x itself (a copy: an autograd node must not hand an input back as an output)
+                s = x2.clone()
+            ctx.save_for_backward(s, mean, rstd, w, rowscale)
+            ctx.adt, ctx.shp, ctx.rps = adt, x.shape, rps
+            ctx.have = (y is not None, ybias is not None, z is not None)
+            ctx.dts = (x.dtype, y.dtype if y is not None else None, z.dtype if z is not None else None, w.dtype)
+            return s.view(x.shape), h.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, ds, dh):
+        with torch.autocast("cuda", enabled=False):
+            s, mean, rstd, w, rowscale = ctx.saved_tensors
+            adt = ctx.adt
+            R, C = s.shape
+            has_y, has_yb, has_z = ctx.have
+            dh2 = dh.reshape(R, C).to(adt).contiguous() if dh is not None else torch.zeros(R, C, dtype=adt, device=s.device)
+            gin = ds.reshape(R, C).to(adt).contiguous() if ds is not None else None
+            dx = torch.empty_like(s)
+            nsum = 3 if has_yb else 2
+            dy = torch.empty_like(s) if (has_y and rowscale is not None) else None
+            nrows = lib.gm3d_ln_plain_partial_rows(R)
+            part = torch.empty(nrows, nsum * C, dtype=torch.float32, device=s.device)
+            _launch("gm3d_add_ln_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_bwd, _ptr(dh2), _ptr(gin), _ptr(s), _ptr(mean),
+                    _ptr(rstd), _ptr(_c32(w)), _ptr(rowscale) if has_y else None, int(ctx.rps), _ptr(dx), _ptr(dy), _ptr(part), nsum, R, C,
+                    _DT[adt], _stream())
+            gb = _finish(part, nrows, nsum * C)
+            xdt, ydt, zdt, wdt = ctx.dts
+            gx = dx.view(ctx.shp)
+            gy = (dy if dy is not None else dx).view(ctx.shp).to(ydt) if has_y else None
+            return (gx.to(xdt), gy, gb[2 * C:].clone() if has_yb else None, None, gx.to(zdt) if has_z else None, gb[:C].to(wdt),
+                    gb[C:2 * C].to(wdt), None, None)
+
+
+class ResidualTailFn(torch.autograd.Function):
+    """out = x + rowscale[sample] * (y + ybias): the last residual sum of a block stack (no LayerNorm behind it) on the same
+    kernels as AddLayerNormFn -- the gradient of ybias is our own column sum (PyTorch's reduction over B*T rows is not
+    hipGraph-replay-safe on this stack: DESIGN 3c; it came back non-finite from the second replay of the Point-M2AE step)."""
+
+    @staticmethod
+    def forward(ctx, x, y, ybias, rowscale, adt):
+        with torch.autocast("cuda", enabled=False):
+            C = x.shape[-1]
+            x2 = x.reshape(-1, C).to(adt).contiguous()
+            R = x2.shape[0]
+            y2 = y.reshape(R, C).to(adt).contiguous()
+            rps = R // rowscale.shape[0] if rowscale is not None else 1
+            s = torch.empty_like(x2)
+            _launch("gm3d_add_ln_fwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_fwd, _ptr(x2), _ptr(y2), _ptr(_c32(ybias)),
+                    _ptr(rowscale), int(rps), None, None, None, 0.0, _ptr(s), None, None, None, R, C, _DT[adt], _stream())
+            ctx.save_for_backward(rowscale)
+            ctx.adt, ctx.shp, ctx.rps, ctx.dts = adt, x.shape, rps, (x.dtype, y.dtype)
+            return s.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, ds):
+        with torch.autocast("cuda", enabled=False):
+            (rowscale,) = ctx.saved_tensors
+            adt = ctx.adt
+            C = ctx.shp[-1]
+            gin = ds.reshape(-1, C).to(adt).contiguous()
+            R = gin.shape[0]
+            dx = torch.empty_like(gin)
+            dy = torch.empty_like(gin) if rowscale is not None else None
+            nrows = lib.gm3d_ln_plain_partial_rows(R)
+            part = torch.empty(nrows, 3 * C, dtype=torch.float32, device=gin.device)
+            dummy = torch.ones(max(R, C), dtype=torch.float32, device=gin.device)     # mean / rstd / gamma of a LayerNorm that is not there
+            _launch("gm3d_add_ln_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_bwd, None, _ptr(gin), _ptr(gin), _ptr(dummy),
+                    _ptr(dummy), _ptr(dummy), _ptr(rowscale), int(ctx.rps), _ptr(dx), _ptr(dy), _ptr(part), 3, R, C, _DT[adt], _stream())
+            gb = _finish(part, nrows, 3 * C)
+            xdt, ydt = ctx.dts
+            return dx.view(ctx.shp).to(xdt), (dy if dy is not None else dx).view(ctx.shp).to(ydt), gb[2 * C:].clone(), None, None
+
+
+class BiasGeluFn(torch.autograd.Function):
+    """g = GELU(f + bias) (exact erf) on csrc/rowops.hip's streaming kernels, any width % 8 == 0; the backward also yields the bias
+    gradient (fc1's: that Linear runs without a bias)."""
+
+    @staticmethod
+    def forward(ctx, f, bias, adt):
+        from .fused import bias_gelu_fwd
+        with torch.autocast("cuda", enabled=False):
+            C = f.shape[-1]
+            f2 = f.reshape(-1, C).to(adt).contiguous()
+            bf = _c32(bias)
+            g = bias_gelu_fwd(f2, bf, adt)
+            ctx.save_for_backward(f2, bias)
+            ctx.adt, ctx.shp, ctx.fdt = adt, f.shape, f.dtype
+            return g.view(f.shape)
+
+    @staticmethod
+    def backward(ctx, dg):
+        from .fused import bias_gelu_bwd
+        with torch.autocast("cuda", enabled=False):
+            f2, bias = ctx.saved_tensors
+            adt = ctx.adt
+            dg2 = dg.reshape(f2.shape).to(adt).contiguous()
+            df, db = bias_gelu_bwd(dg2, f2, _c32(bias), adt)
+            return df.view(ctx.shp).to(ctx.fdt), db.to(bias.dtype), None
+
+
 def layer_norm_supported(x, C):
     return x.is_cuda and 4 <= C <= 512 and C % 4 == 0 and x.dtype in (torch.float32, torch.bfloat16)
 

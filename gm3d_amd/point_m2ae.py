@@ -34,6 +34,8 @@ from .hierarchical_group import HierarchicalGroup
 
 FUSED_EMBED0 = True
 FUSED_LAYERNORM = True
+FUSED_BLOCKS = True       # block stacks: residual sums inside the LayerNorm kernel, bias + GELU as one pass, biases of proj / fc2 added
+#                           (and their gradients summed) by the LayerNorm kernels -- heads.AddLayerNormFn / BiasGeluFn; any width
 ACT_TAPS = None           # tests set this to a list: the sign pattern (pre-activation > 0) of every ReLU / LeakyReLU of a grad-enabled
 #                           forward on the per-op path, in call order (six token-embed ReLUs, the loss head's LeakyReLU, two
 #                           token-propagation ReLUs)
@@ -182,14 +184,14 @@ class MaskedAttention(nn.Module):
         self.qkv = Linear(dim, dim * 3, bias=False)
         self.proj = Linear(dim, dim)
 
-    def forward(self, x, bits):
+    def forward(self, x, bits, proj_bias=True):
         qkv = self.qkv(x)
         hd = x.shape[-1] // self.num_heads
         if bits is None and hd == 64 and x.shape[1] <= 128:
             a = ops.attention(qkv, self.num_heads, self.scale)              # the Point-MAE kernel (whole head in one workgroup)
         else:
             a = ops.attention_masked(qkv, bits, self.num_heads, self.scale)
-        return self.proj(a)
+        return self.proj(a) if proj_bias else _linear(a, self.proj.weight, None)
 
 
 class MaskedBlock(nn.Module):
@@ -212,9 +214,34 @@ class BlockStack(nn.Module):
         self.blocks = nn.ModuleList([MaskedBlock(dim, num_heads, dpr[i]) for i in range(depth)])
 
     def forward(self, x, pos, bits=None):
+        if FUSED_BLOCKS and x.is_cuda:
+            from . import heads
+            if heads.layer_norm_supported(x, x.shape[-1]) and x.shape[-1] % 8 == 0:
+                return self._forward_fused(x, pos, bits)
         for blk in self.blocks:                 # the position is re-added before every block, like Point-MAE
             x = blk(x + pos, bits)
         return x
+
+    def _forward_fused(self, x, pos, bits):
+        """The same blocks with every residual sum formed inside the following LayerNorm's kernel:
+            s, h = AddLN(s, pending branch output (+ its Linear's bias, x its DropPath factor), pos)     block input + norm1
+            s, h = AddLN(s, proj output (+ proj.bias, x DropPath factor))                                  norm2
+            pending = fc2(GELU(fc1(h) + fc1.bias))   -- bias and GELU one pass; fc2's bias joins the next AddLN
+        15 of the ~20 elementwise launches per block (forward + backward) and the separate bias-gradient sums disappear."""
+        from . import heads
+        adt = heads._adt()
+        B = x.shape[0]
+        s, y, yb, rs = x, None, None, None
+        for blk in self.blocks:
+            p = blk.drop_path.drop_prob if isinstance(blk.drop_path, M.DropPath) else 0.0
+            s, h = heads.AddLayerNormFn.apply(s, y, yb, rs, pos, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, adt)
+            a = blk.attn(h, bits, proj_bias=False)
+            rs1 = M.drop_path_scale(B, p, blk.training, x.device)
+            s, h = heads.AddLayerNormFn.apply(s, a, blk.attn.proj.bias, rs1, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, adt)
+            g = heads.BiasGeluFn.apply(_linear(h, blk.mlp.fc1.weight, None), blk.mlp.fc1.bias, adt)
+            y, yb = _linear(g, blk.mlp.fc2.weight, None), blk.mlp.fc2.bias
+            rs = M.drop_path_scale(B, p, blk.training, x.device)
+        return heads.ResidualTailFn.apply(s, y, yb, rs, adt)
 
 
 class TokenPropagation(nn.Module):
@@ -331,7 +358,12 @@ class PointM2AE(nn.Module):
         x2 = self.encoder_norms[2](enc[2])
         if noaug:
             return x2
-        xc = torch.where(vis2.unsqueeze(-1), x2, self.mask_token.to(x2.dtype).expand(B, self.num_group, -1))
+        if x2.is_cuda:       # the token's gradient = a column sum over B*64 rows: our own kernel (replay-safe), not torch's reduction
+            from . import heads
+            mtok = heads.ExpandRowsFn.apply(self.mask_token, B, self.num_group, x2.dtype)
+        else:
+            mtok = self.mask_token.to(x2.dtype).expand(B, self.num_group, -1)
+        xc = torch.where(vis2.unsqueeze(-1), x2, mtok)
         xc = self.h_decoder[0](xc, self.decoder_pos_embeds[0](centers[2]).to(xc.dtype))
         h = self.loss_pred_head
         if xc.is_cuda:

@@ -139,6 +139,21 @@ int gm3d_ln_plain_fwd(const void *x, const float *gamma, const float *beta, floa
                       int C, int dtype, gm3d_stream_t stream);
 int gm3d_ln_plain_bwd(const void *dh, const void *x, const float *mean, const float *rstd, const float *gamma, void *dx,
                       float *partial, int R, int C, int dtype, gm3d_stream_t stream);
+/* The same LayerNorm with the residual sum formed in the kernel (the pre-norm blocks of the hierarchical encoder / decoder, any
+ * width 4 <= C <= 512, C % 4 == 0: Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99 dims 96 / 192 / 384):
+ *   s = x + rowscale[row / rows_per_sample] * (y + ybias) + z   (y, ybias, rowscale, z optional; s_out required with y or z),
+ *   h = LayerNorm(s as stored).   One pass instead of two or three elementwise launches + a LayerNorm.
+ * gamma == NULL: the sum only (the tail of a block stack); gm3d_add_ln_bwd with dh == NULL is its backward (dx = gin, dy, and the
+ * column sum of dy). */
+int gm3d_add_ln_fwd(const void *x, const void *y, const float *ybias, const float *rowscale, int rows_per_sample, const void *z,
+                    const float *gamma, const float *beta, float eps, void *s_out, void *h, float *mean, float *rstd, int R, int C,
+                    int dtype, gm3d_stream_t stream);
+/* Its backward: dx = gin + LayerNorm-backward(dh) (gin optional: the gradient arriving at s from the next residual sum), dy =
+ * rowscale * dx (optional), partial (gm3d_ln_plain_partial_rows(R), nsum, C): [0] dgamma, [1] dbeta and, with nsum == 3, [2]
+ * sum_rows dy = the gradient of ybias. */
+int gm3d_add_ln_bwd(const void *dh, const void *gin, const void *x, const float *mean, const float *rstd, const float *gamma,
+                    const float *rowscale, int rows_per_sample, void *dx, void *dy, float *partial, int nsum, int R, int C, int dtype,
+                    gm3d_stream_t stream);
 
 /* ---- Row-wise fused passes around the transformer-block GEMMs (gm3d_amd/csrc/rowops.hip) ------------
  * Together they restate timm-0.4.5 Block.forward (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146)

@@ -224,3 +224,48 @@ def test_m2ae_bf16_mode_tracks_fp32_mode():
     if bool((ref["mask"] == got["mask"]).all()):
         for k in ("loss_chfr", "loss_learn"):
             assert abs(float(ref[k]) - float(got[k])) <= 3e-2 * abs(float(ref[k])), k
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_fused_block_stack_equals_per_op_blocks(bf16):
+    """point_m2ae.BlockStack with the residual sums inside the LayerNorm kernels (FUSED_BLOCKS) against the per-op blocks on the same
+    weights, DropPath factors injected: outputs and every parameter / input gradient.  fp32: 2e-5; bf16: the fused path rounds a
+    residual sum once where the per-op path rounds twice (2e-2 of the tensor scale)."""
+    from contextlib import nullcontext
+    from gm3d_amd import models_mae_learn_loss as MM
+    from gm3d_amd import ops
+    from gm3d_amd import point_m2ae as P
+    torch.manual_seed(0)
+    B, T, C = 4, 256, 192
+    stack = P.BlockStack(C, 3, 6, [0.0, 0.05, 0.1]).cuda().train()
+    x = torch.randn(B, T, C, device="cuda")
+    pos = torch.randn(B, T, C, device="cuda") * 0.3
+    cen = clouds.pc_norm(torch.randn(B, T, 3)).cuda()
+    vis = torch.rand(B, T, device="cuda") < 0.7
+    bits = ops.radius_mask_bits(cen, vis, 0.64)
+    draws = [(torch.rand(B, device="cuda") > 0.2).float() / 0.8 for _ in range(6)]
+    res = {}
+    was, was_dp, was_dpm = P.FUSED_BLOCKS, MM.drop_path_scale, MM.drop_path
+    try:
+        for fused in (True, False):
+            P.FUSED_BLOCKS = fused
+            it = iter(draws)
+            MM.drop_path_scale = lambda B_, p, training, device: next(it) if p > 0 else None
+            MM.drop_path = lambda t, p, training: t * next(it).view(-1, 1, 1).to(t.dtype) if p > 0 else t      # the per-op DropPath module
+            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+            for p_ in stack.parameters():
+                p_.grad = None
+            with (torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()):
+                out = stack(xi.bfloat16() if bf16 else xi, pi.bfloat16() if bf16 else pi, bits)
+            keep = vis.unsqueeze(-1).float()                   # rows of invisible tokens are garbage by design: not compared
+            (out.float() * keep * torch.linspace(0.5, 1.5, C, device="cuda")).sum().backward()
+            res[fused] = (out.detach().float() * keep, xi.grad.clone(), pi.grad.clone(),
+                          {k: v.grad.detach().clone() for k, v in stack.named_parameters()})
+    finally:
+        P.FUSED_BLOCKS, MM.drop_path_scale, MM.drop_path = was, was_dp, was_dpm
+    tol = 2e-2 if bf16 else 2e-5
+    rel = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-12)
+    assert rel(res[True][0], res[False][0]) <= tol
+    assert rel(res[True][1], res[False][1]) <= 2 * tol and rel(res[True][2], res[False][2]) <= 2 * tol
+    for k, v in res[False][3].items():
+        assert rel(res[True][3][k], v) <= (4e-2 if bf16 else 5e-5), k

@@ -150,3 +150,58 @@ def test_plain_layernorm_any_width(R, C, dtype):
     assert float((x.grad.double() - x64.grad).abs().max()) <= tol * max(1.0, float(x64.grad.abs().max()))
     assert float((w.grad.double() - w64.grad).abs().max()) <= 2e-5 * max(1.0, float(w64.grad.abs().max()))
     assert float((b.grad.double() - b64.grad).abs().max()) <= 2e-5 * max(1.0, float(b64.grad.abs().max()))
+
+
+@pytest.mark.parametrize("adt,tol", [(torch.float32, 2e-5), (torch.bfloat16, 2e-2)])
+@pytest.mark.parametrize("C", [96, 192, 384, 100, 512])
+@pytest.mark.parametrize("form", ["plain", "xz", "xy", "xybias_scale", "all"])
+def test_add_layer_norm_against_fp64(adt, tol, C, form):
+    """heads.AddLayerNormFn: s = x + rowscale[sample] * (y + ybias) + z, h = LayerNorm(s), forward and every gradient (x, y, ybias, z,
+    gamma, beta) against the same expression in fp64 -- the pre-norm residual sums of the hierarchical encoder's blocks (widths
+    96 / 192 / 384, Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:60-75) and odd widths."""
+    from gm3d_amd import heads
+    B, T = 6, 37
+    g = torch.Generator(device="cuda").manual_seed(C + len(form))
+    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
+    x = rnd(B, T, C).to(adt).requires_grad_(True)
+    y = rnd(B, T, C).to(adt).requires_grad_(True) if form in ("xy", "xybias_scale", "all") else None
+    z = rnd(B, T, C).to(adt).requires_grad_(True) if form in ("xz", "all") else None
+    yb = (rnd(C) * 0.5).requires_grad_(True) if form in ("xybias_scale", "all") else None
+    rs = (torch.rand(B, device="cuda", generator=g) > 0.3).float() / 0.7 if form in ("xybias_scale", "all") else None
+    w = (1 + 0.2 * rnd(C)).requires_grad_(True)
+    b = (0.2 * rnd(C)).requires_grad_(True)
+    s, h = heads.AddLayerNormFn.apply(x, y, yb, rs, z, w, b, 1e-5, adt)
+    gs, gh = rnd(B, T, C).to(adt), rnd(B, T, C).to(adt)
+    (s.float() * gs.float()).sum().add((h.float() * gh.float()).sum()).backward()
+    d = lambda t: None if t is None else t.detach().double().requires_grad_(True)
+    x6, y6, z6, yb6, w6, b6 = d(x), d(y), d(z), d(yb), d(w), d(b)
+    s6 = x6
+    if y6 is not None:
+        t = y6 + (yb6 if yb6 is not None else 0.0)
+        s6 = s6 + (rs.double().view(B, 1, 1) * t if rs is not None else t)
+    if z6 is not None:
+        s6 = s6 + z6
+    s_st = s6.detach().to(adt).double() + (s6 - s6.detach())          # normalised AS STORED (value of the rounded sum, gradient of the exact one)
+    h6 = torch.nn.functional.layer_norm(s_st, (C,), w6, b6, 1e-5)
+    ((s6 * gs.double()).sum() + (h6 * gh.double()).sum()).backward()
+    rel = lambda a, r: float((a.double() - r).abs().max()) / max(float(r.abs().max()), 1e-12)
+    assert rel(s, s6) <= tol and rel(h, h6) <= tol
+    for name, a, r in (("x", x, x6), ("y", y, y6), ("z", z, z6), ("ybias", yb, yb6), ("gamma", w, w6), ("beta", b, b6)):
+        if a is not None:
+            assert rel(a.grad, r.grad) <= (tol if adt == torch.float32 else 3e-2), (name, rel(a.grad, r.grad))
+
+
+@pytest.mark.parametrize("adt,tol", [(torch.float32, 1e-5), (torch.bfloat16, 2e-2)])
+def test_bias_gelu_fn(adt, tol):
+    from gm3d_amd import heads
+    g = torch.Generator(device="cuda").manual_seed(3)
+    f = torch.randn(300, 768, device="cuda", generator=g).to(adt).requires_grad_(True)
+    bias = torch.randn(768, device="cuda", generator=g).requires_grad_(True)
+    out = heads.BiasGeluFn.apply(f, bias, adt)
+    go = torch.randn(300, 768, device="cuda", generator=g).to(adt)
+    out.backward(go)
+    f6, b6 = f.detach().double().requires_grad_(True), bias.detach().double().requires_grad_(True)
+    ref = torch.nn.functional.gelu(f6 + b6)
+    ref.backward(go.double())
+    rel = lambda a, r: float((a.double() - r).abs().max()) / float(r.abs().max())
+    assert rel(out, ref) <= tol and rel(f.grad, f6.grad) <= tol and rel(bias.grad, b6.grad) <= tol
