@@ -48,6 +48,10 @@ def algorithmic(name, meta):
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
     if name == "gm3d_attention_qkv_fwd":  # the head's q|k|v projection (T x 192 x C) + QK^T + PV per (b,h)
         return "mfma", meta["B"] * meta["H"] * (2.0 * meta["T"] * 192 * meta["C"] + 4.0 * meta["T"] ** 2 * 64), "FLOP"
+    if name == "gm3d_attention_masked_fwd":   # masked attention of the hierarchical encoder: the dense count (blocked pairs are computed too)
+        return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * meta["HD"], "FLOP"
+    if name == "gm3d_attention_masked_bwd":
+        return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * meta["HD"], "FLOP"
     if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
     if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMMs (+ epilogues; register-prefetch and LDS-DMA ring forms): 2*M*N*K flop

@@ -5,14 +5,15 @@ from types import SimpleNamespace
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gm3d_amd import engine_pretrain as E, point_m2ae as P
-from bench import make_clouds
+from bench import make_clouds, algorithmic
+from gm3d_amd import ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
 a = ap.parse_args()
-E.enable_tuned_gemms()
+E.enable_tuned_gemms()        # this model still hands its 96- / 288- / 576-wide products to the library (K % 64 != 0 or N % 128 != 0)
 torch.manual_seed(0)
 model = P.PointM2AE().cuda().train()
 ema = E.ModelEma(model, 0.999)
@@ -55,4 +56,23 @@ try:
                 execution="hipGraph replay")
 except Exception as ex:
     line.update(value=a.batch / t_eager, ms_per_step=t_eager * 1e3, execution="eager (capture failed: %s)" % str(ex)[:100])
+# per-kernel rooflines of the hand-written kernels (HIP events around every launch of two eager steps): the masked attention's
+# fraction of the bf16 MFMA peak (dense flop count: blocked pairs are computed too) and the GEMM families'
+probe = ops.KernelTimer()
+ops.set_kernel_timer(probe)
+for i in range(2):
+    eager(i)
+ops.set_kernel_timer(None)
+roof = {}
+for n, v in probe.summary().items():
+    try:
+        b_, _, unit = algorithmic(n, v["meta"])
+        work = sum(algorithmic(n, m)[1] for _, m in v["per_launch"])
+    except Exception:
+        continue
+    rate = work / (v["total_ms"] * 1e-3)
+    roof[n] = {"bound": b_, "achieved": round(rate / (1e9 if b_ == "hbm" else 1e12), 2), "unit": "GB/s" if b_ == "hbm" else "TFLOP/s",
+               "frac": round(rate / (8e12 if b_ == "hbm" else 2.5e15), 4), "launches_per_step": v["launches"] / 2,
+               "ms_per_step": round(v["total_ms"] / 2, 3)}
+line["kernel_rooflines"] = dict(sorted(roof.items(), key=lambda kv: -kv[1]["ms_per_step"])[:10])
 print(json.dumps(line))
