@@ -237,4 +237,7 @@ def test_point_mae_with_256_groups_runs_fused_and_matches_per_op():
         # the K=3 conv and the BatchNorm behind it: a small difference of large sums over 8192 rows (the fused node sums in fp64,
         # the module in fp32): 3e-4, as in tests/test_gpu_embed.py; everything else 5e-5
         tol = 3e-4 if "encoder.first_conv" in k else 5e-5
-        assert float((res[True][1][k] - v).abs().max()) <= tol * max(float(v.abs().max()), 1e-3 * gs), k
+        # a conv bias in front of a BatchNorm has an exactly zero gradient: the fused node returns zeros, the modules the rounding
+        # residue of cancelling sums (1e-6 of the largest gradient) -> measured against the largest gradient, not against itself
+        floor = 3e-2 * gs if (".encoder." in k and k.endswith("conv.0.bias")) else 1e-3 * gs
+        assert float((res[True][1][k] - v).abs().max()) <= tol * max(float(v.abs().max()), floor), k
