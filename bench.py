@@ -29,7 +29,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r02_pmc_fetch_write_per_launch.json"     # tools/pmc_summary.py over the two --pmc passes of this bench (profiles/README.md)
+PMC_FILE = "r03_pmc_fetch_write_per_launch.json"     # tools/pmc_summary.py over the two --pmc passes of this bench (profiles/README.md)
+PMC_SOURCES = "r03_pmc_sources.json"                 # {"sha16": hash of gm3d_amd/csrc at the time of those passes} -> staleness is visible
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense
 
 # SURVEY.md 8(d) per-unit algorithmic figures (bytes unless noted) -> per launch
@@ -116,6 +117,26 @@ def pmc_traffic(kernel, dtype, metas=()):
     if not n:
         return None
     return sum(r["launches"] * (2.0 * r["FETCH_SIZE_KB_avg"] + r["WRITE_SIZE_KB_avg"]) * 1024.0 for r in rows) / n
+
+
+def kernel_sources_sha16():
+    """sha256 over gm3d_amd/csrc/* (sorted by name): identifies the kernel code a PMC summary was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "gm3d_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_source():
+    """Where roofline.traffic comes from and whether the kernels have changed since: the counters are NOT collected in this run
+    (rocprofv3 --pmc passes are separate, profiles/README.md)."""
+    path = os.path.join(ROOT, "profiles", PMC_SOURCES)
+    now = kernel_sources_sha16()
+    then = json.load(open(path)).get("sha16") if os.path.exists(path) else None
+    return {"file": "profiles/" + PMC_FILE, "kernel_sources_sha16_then": then, "kernel_sources_sha16_now": now, "stale": then != now}
 
 
 def make_clouds(B, N, seed, device):
@@ -472,7 +493,8 @@ def main():
             "roofline": {"kernel": dominant, "bound": bound, "achieved": achieved, "peak": peak, "unit": runit,
                          "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype, [m for _, m in tsum["per_launch"]]),
                          "avg_launch_us": raw_avg_ms * 1e3, "empty_bracket_us": overhead_ms * 1e3, "launches_timed": tsum["launches"],
-                         "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing},
+                         "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing,
+                         "traffic_source": pmc_source()},
             "execution": ("hipGraph replay" + ((" (4 graphs: segment all-reduces overlap the next backward segment)" if segmented else
                                              " (fwd+bwd | all-reduce | update)") if use_dist else "")) if use_graph
             else (graph_note or "eager"),

@@ -28,6 +28,7 @@ SOURCES = {
     "gemm_nt.hip": [],
     "gemm_ring.hip": [],
     "gemm_dma.hip": [],
+    "gemm_ws.hip": [],
     "attention_masked.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

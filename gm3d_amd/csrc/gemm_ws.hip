@@ -1,0 +1,280 @@
+// C[M,N] = A[M,K] . W[N,K]^T (+ bias[N]), bf16 in / fp32 accumulate / bf16 out -- the TALL members of the path's GEMM family: the
+// mini-PointNet convolutions over the B*G*k = 262,144 point rows (102,400 for the student's visible groups) and their input
+// gradients, K <= 512, N <= 512.
+//
+// Beneath: Encoder.first_conv.3 / second_conv.0 / second_conv.3 (Conv1d(k=1): Point-MAE_SA3D/models_mae_learn_loss.py:876-882) with the
+// max over each group's 32 points (:893,897), and the input gradients autograd derives for them.
+//
+// Why a kernel of their own (MI355X).  These products are HBM streams: A is read once and C written once (400 MB at 256 -> 512),
+// the weights are 64 .. 384 KiB.  The tiled kernels re-stage a W tile with every output tile, so what each CU pulls from L2 is
+// dominated by W (1.07 GB for 400 MB of HBM traffic at 128 x 128 tiles), and with four K-stages per tile the load latency is
+// exposed tile after tile: 2.8 TB/s (profiles/r03_gemm_kbench.txt: 142 us; the tuned library 115 us).  Here the weights are
+// STATIONARY IN REGISTERS: a workgroup is persistent, each of its NW compute waves keeps the fragments of 32 output columns for
+// the whole K (K/4 VGPRs), and only A moves -- 32-row tiles ([32][K] bf16 = one group of 32 points) through an LDS ring filled
+// by LDS-DMA from dedicated loader waves (their vmcnt counts nothing but those loads, so the ring runs on counted waits while the
+// compute waves' stores drain at their own pace; DEPTH tiles in flight).  Per tile every compute wave multiplies the shared A
+// tile with its resident W fragments (K/16 MFMA 32x32x16, k ascending: the accumulation order of csrc/gemm.hip -> identical
+// bits), the 32 x BN result is staged in LDS as bf16 and leaves as whole rows; the max-pool epilogue reduces the staged tile --
+// exactly one group -- down its 32 rows.  L2 -> CU traffic: A once per column block of 32 NW columns, nothing else.
+#include "common.hpp"
+
+namespace gm3d {
+
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x4 __attribute__((ext_vector_type(4)));
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int ws_f(int row) { return (((row >> 1) & 1) << 2) | (((row >> 2) & 1) << 1) | ((row >> 3) & 1); }
+__device__ __forceinline__ int ws_off(int row, int ch) { return row * 128 + ((ch ^ ws_f(row)) << 4); }
+
+__device__ __forceinline__ void ws_glds16(const void* gsrc, unsigned dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n <= 48 (the immediate must be a constant: one uniform branch)
+__device__ __forceinline__ void ws_wait_vm(int n) {
+#define GM3D_WS_CASE(N_) case N_: asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); break;
+    switch (n) {
+        GM3D_WS_CASE(0) GM3D_WS_CASE(4) GM3D_WS_CASE(8) GM3D_WS_CASE(12) GM3D_WS_CASE(16) GM3D_WS_CASE(24) GM3D_WS_CASE(32)
+        GM3D_WS_CASE(36) GM3D_WS_CASE(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef GM3D_WS_CASE
+}
+
+// KT = K / 64; NW compute waves (32 output columns each: BN = 32 NW); NL loader waves; EPI 0: C = A.W^T (+ bias); EPI 3: max over
+// the tile's 32 rows (+ argmax, bias before or after the pool) into P / ARG, C rows optional (as gm3d_gemm_tn_bf16_pool).
+template <int KT, int NW, int NL, int EPI>
+__global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                     const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N,
+                                                                     int lda, int ldw, int ldc, int tiles_n, bf16_t* __restrict__ P,
+                                                                     uint8_t* __restrict__ ARG, int ldp, int bias_after_pool) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
+    constexpr int BN = 32 * NW;
+    constexpr int TILE = KT * 4096;                 // bytes of one [32][K] A tile: KT swizzled [32][64] images
+    constexpr int NP = 4 * KT;                      // 1-KiB LDS-DMA pieces per tile
+    constexpr int PPL = NP / NL;                    // pieces per loader wave and tile
+    constexpr int DEPTH = (48 / PPL) < 4 ? (48 / PPL) : 4;      // tiles in flight (vmcnt is a 6-bit counter)
+    constexpr int NT = DEPTH + 1;                   // ring slots
+    static_assert(NP % NL == 0 && DEPTH >= 2, "loader split");
+    unsigned char* stage = wsm + NT * TILE;         // [32][BN] bf16 as BN / 64 swizzled [32][64] images
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // column blocks of one row stream share an XCD's L2
+    const int tile_n = logical % tiles_n, first = logical / tiles_n, stride = gridDim.x / tiles_n;
+    const int tiles_m = (M + 31) >> 5;
+    const int nmine = first < tiles_m ? (tiles_m - first + stride - 1) / stride : 0;
+    const int n0 = tile_n * BN;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wsm;
+
+    if (w >= NW) {
+        // ------------------------------------------------------------------ loader wave(s): nothing but LDS-DMA and barriers
+        const int lw = w - NW, prow = lane >> 3, pslot = lane & 7;
+        auto issue = [&](int i) {
+            const int m0 = (first + i * stride) << 5;
+            const unsigned base = lds0 + (i % NT) * TILE;
+#pragma unroll
+            for (int q = 0; q < PPL; ++q) {
+                const int p = lw * PPL + q, kt = p >> 2, row = 8 * (p & 3) + prow;
+                const int am = m0 + row < M ? m0 + row : M - 1;      // rows past M: clamped (their outputs are never stored)
+                ws_glds16(A + (size_t)am * lda + 64 * kt + ((pslot ^ ws_f(row)) << 3), base + 1024 * p);
+            }
+        };
+        for (int d = 0; d < DEPTH && d < nmine; ++d) issue(d);
+        for (int i = 0; i < nmine; ++i) {
+            // the slot of tile i + DEPTH is the one tile i - 1 was read from: every compute wave finished with it before the
+            // second barrier of iteration i - 1, which this wave has passed
+            if (i + DEPTH < nmine) issue(i + DEPTH);
+            const int ahead = nmine - 1 - i < DEPTH ? nmine - 1 - i : DEPTH;
+            ws_wait_vm(ahead * PPL);
+            __builtin_amdgcn_s_barrier();            // B1: tile i has landed (all loader waves) -> visible to the compute waves
+            __builtin_amdgcn_s_barrier();            // B2: the compute waves are done READING tile i (and have staged its rows)
+        }
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves: W fragments resident in registers
+    wbf16x8 wreg[KT][4];
+    {
+        const bf16_t* wp = W + (size_t)(n0 + 32 * w + r) * ldw + 8 * hh;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wreg[kt][s] = *reinterpret_cast<const wbf16x8*>(wp + 64 * kt + 16 * s);
+    }
+    float bq[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bq[q][e] = bias ? bias[n0 + 32 * w + 8 * q + 4 * hh + e] : 0.f;
+    const bool bias_in_tile = EPI == 0 || !bias_after_pool;
+    constexpr int CTHREADS = 64 * NW;
+
+    for (int i = 0; i < nmine; ++i) {
+        const int m0 = (first + i * stride) << 5;
+        __builtin_amdgcn_s_barrier();                // B1
+        const unsigned char* as = wsm + (i % NT) * TILE;
+        wf32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt) {
+            wbf16x8 fa[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const wbf16x8*>(as + kt * 4096 + ws_off(r, 2 * s + hh));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[s], acc, 0, 0, 0);
+        }
+        if (EPI == 3 && !C) __builtin_amdgcn_s_barrier();      // B2 (no rows to stage): tile i's slot may be refilled from here on
+        // acc[4 q + e]: row r, column 32 w + 8 q + 4 hh + e, rounded to bf16 (+ bias where it belongs before the rounding)
+        bf16_t ov[4][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ov[q][e] = (bf16_t)(acc[4 * q + e] + (bias_in_tile ? bq[q][e] : 0.f));
+        if (EPI == 3) {
+            // max over the tile's 32 rows = over the 32 lanes of a half-wave, per register: ONE 32-bit key per column --
+            // (order-preserving image of the bf16 value) << 8 | (31 - row) -- so that a plain unsigned max picks the largest value
+            // and, among equal values, the lowest row: the "first maximum wins" of gm3d_group_max_fwd (-0 counts as +0).  Five
+            // DPP steps per key; the result sits in lanes 16..31 / 48..63.
+            unsigned key[4][4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    unsigned u = (unsigned)__builtin_bit_cast(unsigned short, ov[q][e]);
+                    u = u == 0x8000u ? 0u : u;
+                    const unsigned k16 = (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
+                    unsigned k = (k16 << 8) | (unsigned)(31 - r);
+                    unsigned t;
+                    t = dpp_u32<0xB1>(k, k); k = t > k ? t : k;
+                    t = dpp_u32<0x4E>(k, k); k = t > k ? t : k;
+                    t = dpp_u32<0x141>(k, k); k = t > k ? t : k;
+                    t = dpp_u32<0x140>(k, k); k = t > k ? t : k;
+                    t = dpp_u32<0x142, 0xA>(k, k); k = t > k ? t : k;
+                    key[q][e] = k;
+                }
+            if (r == 31 && m0 < M) {
+                const size_t o = (size_t)(m0 >> 5) * ldp + n0 + 32 * w + 4 * hh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    wbf16x4 pv;
+                    unsigned ai = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned k16 = key[q][e] >> 8;
+                        const unsigned short u = (unsigned short)((k16 & 0x8000u) ? (k16 & 0x7fffu) : (~k16 & 0xffffu));
+                        float v = (float)__builtin_bit_cast(bf16_t, u);
+                        if (bias_after_pool) v += bq[q][e];
+                        pv[e] = (bf16_t)v;
+                        ai |= (31u - (key[q][e] & 0xffu)) << (8 * e);
+                    }
+                    *reinterpret_cast<wbf16x4*>(P + o + 8 * q) = pv;
+                    *reinterpret_cast<unsigned*>(ARG + o + 8 * q) = ai;
+                }
+            }
+            if (!C) continue;                        // no rows wanted (second_conv.3): nothing is staged
+        }
+        {
+            unsigned char* img = stage + ((32 * w) >> 6) * 4096;
+            const int cbase = ((32 * w) & 63) >> 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                wbf16x4 pk;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) pk[e] = ov[q][e];
+                *reinterpret_cast<wbf16x4*>(img + ws_off(r, cbase + q) + 8 * hh) = pk;
+            }
+        }
+        __syncthreads();                             // B2: the tile's rows are staged (LDS writes drained; the loader waves pass through)
+        if (EPI == 0 || C) {
+            // 32 rows x BN / 8 chunks of 16 bytes: whole rows leave in 16-byte pieces (BN / 8 lanes per row)
+            constexpr int CH = BN / 8;
+#pragma unroll
+            for (int c0 = 0; c0 < 32 * CH; c0 += CTHREADS) {
+                const int c = c0 + tid;
+                if (c < 32 * CH) {
+                    const int row = c / CH, chunk = c - row * CH;
+                    if (m0 + row < M) {
+                        const uint4 raw = *reinterpret_cast<const uint4*>(stage + (chunk >> 3) * 4096 + ws_off(row, chunk & 7));
+                        *reinterpret_cast<uint4*>(C + (size_t)(m0 + row) * ldc + n0 + 8 * chunk) = raw;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace gm3d
+
+// grid: one persistent workgroup per CU (a multiple of 8 and of tiles_n; never more than there are tiles)
+static int ws_grid(int tiles_m, int tiles_n) {
+    long long want = (long long)tiles_m * tiles_n;
+    int g = want < 256 ? (int)want : 256;
+    g = (g + 7) / 8 * 8;
+    while (g % tiles_n) g += 8;
+    return g;
+}
+
+static int ws_launch(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* ARG, int M, int N, int K, int lda,
+                     int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!A || !W || (!C && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
+    if (P && (!ARG || M % 32 || ldp % 8 || ldp < N || ((size_t)ARG & 7) || ((size_t)P & 15))) return GM3D_EINVAL;
+    if (K % 64 || K > 512 || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
+    if (((size_t)A | (size_t)W | (size_t)C) & 15) return GM3D_EUNSUPPORTED;
+    if (M == 0) return GM3D_OK;
+    const int tiles_m = (M + 31) / 32;
+    hipStream_t st = (hipStream_t)stream;
+#define GM3D_WS_LAUNCH(KT, NW, NL, EPI)                                                                                   \
+    {                                                                                                                    \
+        constexpr int PPL_ = 4 * KT / NL, DEPTH_ = (48 / PPL_) < 4 ? (48 / PPL_) : 4;                                    \
+        const size_t lds = (size_t)(DEPTH_ + 1) * KT * 4096 + (size_t)64 * 32 * NW;                                      \
+        const int tiles_n = N / (32 * NW), grid = ws_grid(tiles_m, tiles_n);                                             \
+        static LdsAttr attr;                                                                                             \
+        if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI>, lds)) return GM3D_ELAUNCH;                     \
+        hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI>), dim3(grid), dim3(64 * (NW + NL)), lds, st, (const bf16_t*)A, \
+                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp,       \
+                           bias_after_pool);                                                                             \
+        GM3D_CHECK_LAUNCH();                                                                                             \
+        return GM3D_OK;                                                                                                  \
+    }
+    // the shapes of the mini-PointNet (models_mae_learn_loss.py:872-883) and of its backward; anything else: EUNSUPPORTED
+    if (P) {
+        if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 3)          // first_conv.3 + max-pool
+        if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 3)          // second_conv.3 + max-pool (two column blocks of 192)
+        return GM3D_EUNSUPPORTED;
+    }
+    if (K == 256 && N == 512) GM3D_WS_LAUNCH(4, 8, 1, 0)              // second_conv.0 on the local half (two column blocks)
+    if (K == 512 && N == 256) GM3D_WS_LAUNCH(8, 4, 2, 0)              // its input gradient (128 VGPRs of W per wave: 6 waves per CU)
+    if (K == 384 && N == 512) GM3D_WS_LAUNCH(6, 8, 2, 0)              // second_conv.3's input gradient
+    if (K == 256 && N == 128) GM3D_WS_LAUNCH(4, 4, 1, 0)              // first_conv.3's input gradient
+    if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 0)
+    if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 0)
+#undef GM3D_WS_LAUNCH
+    return GM3D_EUNSUPPORTED;
+}
+
+extern "C" int gm3d_gemm_tn_bf16_ws(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int lda, int ldw,
+                                    int ldc, gm3d_stream_t stream) {
+    if (!C) return GM3D_EINVAL;
+    return ws_launch(A, W, bias, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_ws_pool(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* arg, int M, int N,
+                                         int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream) {
+    if (!P || !arg) return GM3D_EINVAL;
+    return ws_launch(A, W, bias, C, P, arg, M, N, K, lda, ldw, ldc, ldp, bias_after_pool, stream);
+}
+
+// 1 when gm3d_gemm_tn_bf16_ws[_pool] has an instantiation for (N, K)
+extern "C" int gm3d_gemm_ws_supported(int N, int K, int pool) {
+    if (pool) return (K == 128 && N == 256) || (K == 512 && N == 384);
+    return (K == 256 && N == 512) || (K == 512 && N == 256) || (K == 384 && N == 512) || (K == 256 && N == 128) ||
+           (K == 128 && N == 256) || (K == 512 && N == 384);
+}

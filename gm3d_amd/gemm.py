@@ -152,6 +152,28 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
     return f_out, g_out
 
 
+USE_WS = True             # tall products (M >= 32768) of the mini-PointNet shapes on the weight-stationary kernel (csrc/gemm_ws.hip):
+#                           40 / 104 / 55 / 104 / 43 us against 53 / 142 / 76 / 112 / 47 on the tiled kernels (r03 table), -0.13 ms per step
+USE_WS_POOL = False       # its max-pool epilogue (a DPP reduction over the 32 rows of the accumulator tile) is correct but costs ~450
+#                           VALU instructions per wave and tile: 102 / 218 us against 77 / 143 on csrc/gemm_dma.hip (tools/pool_kbench.py)
+
+
+def ws_supported(x, w, pool=False):
+    return ((USE_WS_POOL if pool else USE_WS) and supported(x, w) and x.shape[0] >= 32768
+            and bool(lib.gm3d_gemm_ws_supported(w.shape[0], w.shape[1], int(pool))))
+
+
+def linear_tn_ws(x, w, bias=None, out=None):
+    """linear_tn through the weight-stationary streaming kernel (csrc/gemm_ws.hip): bit-identical; for the tall mini-PointNet products."""
+    M, K = x.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
+    _launch("gm3d_gemm_tn_bf16_ws", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws, _ptr(x), _ptr(w), _ptr(bias), _ptr(out), M, N, K,
+            x.stride(0), w.stride(0), out.stride(0), _stream())
+    return out
+
+
 def linear_tn_dmaw(x, w, bias=None, out=None, bm=128, bn=256):
     """linear_tn through csrc/gemm_dma.hip with a bm x bn tile (bn = 128 / 192 / 256 columns, N % bn == 0): bit-identical."""
     M, K = x.shape
@@ -199,6 +221,8 @@ def mm(x, w, bias=None, out=None):
     """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names.  Operands that do not meet the hand-written kernels' layout
     rules (fp32 parity mode, odd widths) go to torch.mm: never on the bf16 step's path (tools/leftover_sites.py lists none)."""
     how = choose(x.shape[0], w.shape[0], w.shape[1]) if supported(x, w) else "lib"
+    if how != "lib" and ws_supported(x, w):
+        return linear_tn_ws(x, w, bias, out)
     if how == "own":
         return linear_tn(x, w, bias, out)
     if how.startswith("ring"):
@@ -247,6 +271,10 @@ def linear_pool(x, w, bias, bias_after_pool, want_rows):
     rows = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_rows else None
     pooled = torch.empty(M // 32, N, dtype=torch.bfloat16, device=x.device)
     arg = torch.empty(M // 32, N, dtype=torch.uint8, device=x.device)
+    if ws_supported(x, w, pool=True):
+        _launch("gm3d_gemm_tn_bf16_ws_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
+                _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), _stream())
+        return rows, pooled, arg
     if POOL_ON_DMA and N % 8 == 0 and (N % 192 == 0 or N % 128 == 0):
         bn = 192 if N % 192 == 0 else 128
         _launch("gm3d_gemm_tn_bf16_dma_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_dma_pool, _ptr(x), _ptr(w), _ptr(bias),

@@ -402,6 +402,17 @@ int gm3d_gemm_tn_bf16_ring(const void *A, const void *W, const float *bias, void
 /* Ring depth of gm3d_gemm_tn_bf16_ring: K-stages requested ahead of the one being multiplied (2 .. 4 for bm = 64, 2 .. 3 for
  * bm = 128; clamped).  Results do not depend on it.  Process-wide; set before capturing a graph. */
 int gm3d_gemm_ring_set_depth(int bm, int depth);
+/* The TALL products of the mini-PointNet (Encoder.first_conv.3 / second_conv.0 / second_conv.3 over the B*G*k = 262,144 point rows,
+ * models_mae_learn_loss.py:876-882, and their input gradients; K <= 512) with the weights STATIONARY IN REGISTERS (csrc/gemm_ws.hip):
+ * persistent workgroups, 32 output columns of W per wave for the whole K, A streamed once per column block through an LDS ring
+ * filled by loader waves.  HBM-bound by design (A in + C out).  Instantiated for (K -> N) = 256 -> 512, 512 -> 256, 384 -> 512,
+ * 256 -> 128, 128 -> 256, 512 -> 384 (gm3d_gemm_ws_supported); results bit-identical to gm3d_gemm_tn_bf16. */
+int gm3d_gemm_tn_bf16_ws(const void *A, const void *W, const float *bias, void *C, int M, int N, int K, int lda, int ldw, int ldc,
+                         gm3d_stream_t stream);
+/* ... with the max-pool epilogue of gm3d_gemm_tn_bf16_pool (one 32-row tile = one group of 32 points): 128 -> 256 and 512 -> 384. */
+int gm3d_gemm_tn_bf16_ws_pool(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N, int K,
+                              int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
+int gm3d_gemm_ws_supported(int N, int K, int pool);
 /* The ring kernel with 96-column tiles (N % 96 == 0): N = 384 -- attn.proj, mlp.fc2 and the input gradients of fc1 / qkv / proj of
  * the timm Block (Point-MAE_SA3D/models/Point_MAE.py:82-125) -- as four column tiles per row block instead of three: 200 / 256
  * workgroups instead of 150 / 192 for 256 CUs, each pulling fewer operand bytes from L2.  Bit-identical results.  bm = 64 or 128. */

@@ -316,3 +316,51 @@ def test_gemm_ring96_equals_ring(M, K, N, bm):
         gemm.linear_tn_ring96(x, w, bias, out=out[:M], bm=bm)
         assert torch.equal(out[:M], want)
         assert bool((out[M:] == 7.0).all())
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 256, 512), (40000, 512, 256), (102400, 384, 512), (70016, 256, 128), (65536, 128, 256),
+                                   (102400, 512, 384), (33, 256, 512), (32 * 257 + 5, 512, 384)])
+def test_gemm_weight_stationary_equals_tiled_kernels(M, K, N):
+    """csrc/gemm_ws.hip (persistent workgroups, W fragments resident in registers, A streamed through an LDS ring by loader waves):
+    the same accumulation order along K as the tiled kernels -> bit-identical products, with and without bias, ragged M, nothing
+    written past row M."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    for bias in (None, b):
+        want = gemm.linear_tn(x, w, bias)
+        out = torch.full((M + 3, N), 7.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn_ws(x, w, bias, out=out[:M])
+        assert torch.equal(out[:M], want)
+        assert bool((out[M:] == 7.0).all())
+    if M >= 32768:
+        assert torch.equal(gemm.mm(x, w, b), want)
+
+
+@pytest.mark.parametrize("groups,K,N,after,rows", [(8192, 128, 256, False, True), (3200, 512, 384, True, False), (1030, 128, 256, False, True),
+                                                   (1025, 512, 384, True, False), (1100, 512, 384, False, True)])
+def test_gemm_weight_stationary_pool_epilogue(groups, K, N, after, rows):
+    """conv + max over each group's 32 rows on the weight-stationary kernel == the same product followed by gm3d_group_max_fwd
+    (values, argmax decisions and the optional rows, bit for bit)."""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    M = groups * 32
+    g = torch.Generator(device="cuda").manual_seed(groups + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) * 0.2
+    full = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if rows else None
+    pooled = torch.empty(groups, N, device="cuda", dtype=torch.bfloat16)
+    arg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
+    check(lib.gm3d_gemm_tn_bf16_ws_pool(_ptr(x), _ptr(w), _ptr(b), _ptr(full), _ptr(pooled), _ptr(arg), M, N, K, K, K, N, N, int(after),
+                                        _stream()), "ws_pool")
+    z = gemm.linear_tn(x, w, None if after else b)
+    if rows:
+        assert torch.equal(full, z)
+    want = torch.empty(groups, N, device="cuda", dtype=torch.bfloat16)
+    warg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
+    check(lib.gm3d_group_max_fwd(_ptr(z), _ptr(b) if after else None, _ptr(want), _ptr(warg), groups, 32, N, 1, _stream()), "gmax")
+    assert torch.equal(pooled, want) and torch.equal(arg, warg)

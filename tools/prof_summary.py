@@ -8,6 +8,12 @@ def cat(n):
     if 'batch_norm' in n: return 'batchnorm'
     if 'layer_norm' in n or 'GammaBeta' in n: return 'layernorm (torch)'
     if 'gm3d::' in n: return 'gm3d:' + n.split('gm3d::')[1].split('(')[0].split('<')[0]
+    if n.startswith('_ZN4gm3d'):          # mangled template instantiations: _ZN4gm3d<len><name>I...
+        import re
+        m = re.match(r'_ZN4gm3d(\d+)', n)
+        if m:
+            k = int(m.group(1)); st = len(m.group(0))
+            return 'gm3d:' + n[st:st + k]
     if 'bfloat16_copy' in n or 'bfloat16tofloat32' in n or 'float32tobfloat16' in n or 'float_copy' in n: return 'dtype-cast'
     if 'reduce_kernel' in n: return 'reduce'
     if 'multi_tensor' in n: return 'optimizer/foreach'
