@@ -75,6 +75,7 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_ws": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_ws_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_ws_supported": [_i, _i, _i],
+    "gm3d_gemm_ws_set_occupancy": [_i],
     "gm3d_gemm_tn_bf16_ring96": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
     constexpr int TILE = KT * 4096;                 // bytes of one [32][K] A tile: KT swizzled [32][64] images
     constexpr int NP = 4 * KT;                      // 1-KiB LDS-DMA pieces per tile
     constexpr int PPL = NP / NL;                    // pieces per loader wave and tile
-    constexpr int DEPTH = (48 / PPL) < 4 ? (48 / PPL) : 4;      // tiles in flight (vmcnt is a 6-bit counter)
+    constexpr int DEPTH = (48 / PPL) < 4 ? (48 / PPL) : 4;      // tiles in flight (vmcnt is a 6-bit counter); 2 measured the same
     constexpr int NT = DEPTH + 1;                   // ring slots
     static_assert(NP % NL == 0 && DEPTH >= 2, "loader split");
     unsigned char* stage = wsm + NT * TILE;         // [32][BN] bf16 as BN / 64 swizzled [32][64] images
@@ -213,9 +213,17 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 }  // namespace gm3d
 
 // grid: one persistent workgroup per CU (a multiple of 8 and of tiles_n; never more than there are tiles)
-static int ws_grid(int tiles_m, int tiles_n) {
+static int WS_WG_PER_CU = 2;      // measurement knob (gm3d_gemm_ws_set_occupancy): persistent workgroups per CU where LDS allows two
+
+extern "C" int gm3d_gemm_ws_set_occupancy(int wg_per_cu) {
+    WS_WG_PER_CU = wg_per_cu < 1 ? 1 : (wg_per_cu > 2 ? 2 : wg_per_cu);
+    return GM3D_OK;
+}
+
+static int ws_grid(int tiles_m, int tiles_n, size_t lds) {
     long long want = (long long)tiles_m * tiles_n;
-    int g = want < 256 ? (int)want : 256;
+    const int cap = (WS_WG_PER_CU == 2 && 2 * lds <= 160 * 1024) ? 512 : 256;
+    int g = want < cap ? (int)want : cap;
     g = (g + 7) / 8 * 8;
     while (g % tiles_n) g += 8;
     return g;
@@ -235,7 +243,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
     {                                                                                                                    \
         constexpr int PPL_ = 4 * KT / NL, DEPTH_ = (48 / PPL_) < 4 ? (48 / PPL_) : 4;                                    \
         const size_t lds = (size_t)(DEPTH_ + 1) * KT * 4096 + (size_t)64 * 32 * NW;                                      \
-        const int tiles_n = N / (32 * NW), grid = ws_grid(tiles_m, tiles_n);                                             \
+        const int tiles_n = N / (32 * NW), grid = ws_grid(tiles_m, tiles_n, lds);                                             \
         static LdsAttr attr;                                                                                             \
         if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI>, lds)) return GM3D_ELAUNCH;                     \
         hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI>), dim3(grid), dim3(64 * (NW + NL)), lds, st, (const bf16_t*)A, \

@@ -413,6 +413,8 @@ int gm3d_gemm_tn_bf16_ws(const void *A, const void *W, const float *bias, void *
 int gm3d_gemm_tn_bf16_ws_pool(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N, int K,
                               int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
 int gm3d_gemm_ws_supported(int N, int K, int pool);
+/* measurement knob: persistent workgroups per CU (1 or 2; two only where the LDS ring allows). Results do not depend on it. */
+int gm3d_gemm_ws_set_occupancy(int wg_per_cu);
 /* The ring kernel with 96-column tiles (N % 96 == 0): N = 384 -- attn.proj, mlp.fc2 and the input gradients of fc1 / qkv / proj of
  * the timm Block (Point-MAE_SA3D/models/Point_MAE.py:82-125) -- as four column tiles per row block instead of three: 200 / 256
  * workgroups instead of 150 / 192 for 256 CUs, each pulling fewer operand bytes from L2.  Bit-identical results.  bm = 64 or 128. */

@@ -60,7 +60,9 @@ if __name__ == "__main__":
                 if N % bn == 0:
                     res["dma%dx%d" % (bm, bn)] = train(lambda x, w, o: gemm.linear_tn_dmaw(x, w, out=o, bm=bm, bn=bn), sets)
         if M >= 32768 and gemm.lib.gm3d_gemm_ws_supported(N, K, 0):
-            res["ws"] = train(lambda x, w, o: gemm.linear_tn_ws(x, w, out=o), sets)
+            for occ in (1, 2):
+                gemm.lib.gm3d_gemm_ws_set_occupancy(occ)
+                res["ws%d" % occ] = train(lambda x, w, o: gemm.linear_tn_ws(x, w, out=o), sets)
         best = min((v, k) for k, v in res.items() if k != "lib")
         hbm = 2.0 * (M * K + M * N + N * K) / 1e6          # MB: A once, C once, W once
         print("M=%6d K=%4d N=%4d  lib %7.1f us | " % (M, K, N, res["lib"]) + "  ".join("%s %.1f" % (k, v) for k, v in res.items() if k != "lib")
