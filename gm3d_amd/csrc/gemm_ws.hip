@@ -82,6 +82,9 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             for (int q = 0; q < PPL; ++q) {
                 const int p = lw * PPL + q, kt = p >> 2, row = 8 * (p & 3) + prow;
                 const int am = m0 + row < M ? m0 + row : M - 1;      // rows past M: clamped (their outputs are never stored)
+#ifdef GM3D_WS_PROBE_NO_LOAD
+                if (i < DEPTH)
+#endif
                 ws_glds16(A + (size_t)am * lda + 64 * kt + ((pslot ^ ws_f(row)) << 3), base + 1024 * p);
             }
         };
@@ -127,71 +130,74 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             wbf16x8 fa[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const wbf16x8*>(as + kt * 4096 + ws_off(r, 2 * s + hh));
+            // EPI 0: the transposed tile (lane = row, registers = 4 x 4 consecutive columns: whole-row staging).  EPI 3: operands
+            // swapped -> lane = COLUMN (lane & 31), registers = 16 of the 32 rows (8 (g >> 2) + 4 hh + (g & 3)), the other 16 in lane ^ 32:
+            // the max over rows is 15 register maxima + one cross-lane step.  Same products, same k order: same bits.
+#ifndef GM3D_WS_PROBE_NO_MFMA
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[s], acc, 0, 0, 0);
+            for (int s = 0; s < 4; ++s)
+                acc = EPI == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], wreg[kt][s], acc, 0, 0, 0)
+                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[s], acc, 0, 0, 0);
+#else
+            acc[0] += (float)fa[0][0] + (float)fa[1][1] + (float)fa[2][2] + (float)fa[3][3] + (float)wreg[kt][0][0];
+#endif
         }
         if (EPI == 3 && !C) __builtin_amdgcn_s_barrier();      // B2 (no rows to stage): tile i's slot may be refilled from here on
-        // acc[4 q + e]: row r, column 32 w + 8 q + 4 hh + e, rounded to bf16 (+ bias where it belongs before the rounding)
-        bf16_t ov[4][4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) ov[q][e] = (bf16_t)(acc[4 * q + e] + (bias_in_tile ? bq[q][e] : 0.f));
         if (EPI == 3) {
-            // max over the tile's 32 rows = over the 32 lanes of a half-wave, per register: ONE 32-bit key per column --
-            // (order-preserving image of the bf16 value) << 8 | (31 - row) -- so that a plain unsigned max picks the largest value
-            // and, among equal values, the lowest row: the "first maximum wins" of gm3d_group_max_fwd (-0 counts as +0).  Five
-            // DPP steps per key; the result sits in lanes 16..31 / 48..63.
-            unsigned key[4][4];
+            // acc[g]: row 8 (g >> 2) + 4 hh + (g & 3), column 32 w + r.  Rounded to bf16 (+ bias where it belongs before the rounding); ONE
+            // 32-bit key per element -- (order-preserving image of the bf16 value) << 16 | (31 - row) -- so that a plain unsigned max picks
+            // the largest value and, among equal values, the lowest row: the "first maximum wins" of gm3d_group_max_fwd (-0 counts as +0).
+            const float bcol = bias ? bias[n0 + 32 * w + r] : 0.f;          // (L1 hit after the first tile)
+            unsigned best = 0;
+            unsigned short rowbits[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    unsigned u = (unsigned)__builtin_bit_cast(unsigned short, ov[q][e]);
-                    u = u == 0x8000u ? 0u : u;
-                    const unsigned k16 = (u & 0x8000u) ? (~u & 0xffffu) : (u | 0x8000u);
-                    unsigned k = (k16 << 8) | (unsigned)(31 - r);
-                    unsigned t;
-                    t = dpp_u32<0xB1>(k, k); k = t > k ? t : k;
-                    t = dpp_u32<0x4E>(k, k); k = t > k ? t : k;
-                    t = dpp_u32<0x141>(k, k); k = t > k ? t : k;
-                    t = dpp_u32<0x140>(k, k); k = t > k ? t : k;
-                    t = dpp_u32<0x142, 0xA>(k, k); k = t > k ? t : k;
-                    key[q][e] = k;
-                }
-            if (r == 31 && m0 < M) {
-                const size_t o = (size_t)(m0 >> 5) * ldp + n0 + 32 * w + 4 * hh;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    wbf16x4 pv;
-                    unsigned ai = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned k16 = key[q][e] >> 8;
-                        const unsigned short u = (unsigned short)((k16 & 0x8000u) ? (k16 & 0x7fffu) : (~k16 & 0xffffu));
-                        float v = (float)__builtin_bit_cast(bf16_t, u);
-                        if (bias_after_pool) v += bq[q][e];
-                        pv[e] = (bf16_t)v;
-                        ai |= (31u - (key[q][e] & 0xffu)) << (8 * e);
-                    }
-                    *reinterpret_cast<wbf16x4*>(P + o + 8 * q) = pv;
-                    *reinterpret_cast<unsigned*>(ARG + o + 8 * q) = ai;
-                }
+            for (int g = 0; g < 16; ++g) {
+                const bf16_t o = (bf16_t)(acc[g] + (bias_in_tile ? bcol : 0.f));
+                rowbits[g] = __builtin_bit_cast(unsigned short, o);
+                unsigned u = (unsigned)rowbits[g] << 16;
+                u = u == 0x80000000u ? 0u : u;
+                const unsigned k = (u ^ (unsigned)(((int)u >> 31) | (int)0x80000000)) & 0xffff0000u;
+                const unsigned key = k | (unsigned)(31 - (8 * (g >> 2) + 4 * hh + (g & 3)));
+                best = key > best ? key : best;
+            }
+            {   // the other 16 rows of this column sit in lane ^ 32
+                const unsigned other = (unsigned)__shfl_xor((int)best, 32);
+                best = other > best ? other : best;
+            }
+            if (hh == 0 && m0 < M) {
+                const unsigned k = best & 0xffff0000u;
+                const unsigned u = (k & 0x80000000u) ? (k & 0x7fff0000u) : (~k & 0xffff0000u);
+                float v = __builtin_bit_cast(float, u);
+                if (bias_after_pool) v += bcol;
+                const size_t o = (size_t)(m0 >> 5) * ldp + n0 + 32 * w + r;
+                P[o] = (bf16_t)v;
+                ARG[o] = (uint8_t)(31u - (best & 0xffu));
             }
             if (!C) continue;                        // no rows wanted (second_conv.3): nothing is staged
-        }
-        {
+            // rows wanted (first_conv.3): this lane's 16 values of column 32 w + r into the staging image, 2 bytes at a time
+            unsigned char* img = stage + ((32 * w) >> 6) * 4096;
+            const int ch = (((32 * w) & 63) + r) >> 3, sub = 2 * (r & 7);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int row = 8 * (g >> 2) + 4 * hh + (g & 3);
+                *reinterpret_cast<unsigned short*>(img + ws_off(row, ch) + sub) = rowbits[g];
+            }
+        } else {
+            // acc[4 q + e]: row r, column 32 w + 8 q + 4 hh + e, rounded to bf16 (+ bias) into the staging images (image = 64 columns)
             unsigned char* img = stage + ((32 * w) >> 6) * 4096;
             const int cbase = ((32 * w) & 63) >> 3;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 wbf16x4 pk;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = ov[q][e];
+                for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[4 * q + e] + bq[q][e]);
                 *reinterpret_cast<wbf16x4*>(img + ws_off(r, cbase + q) + 8 * hh) = pk;
             }
         }
-        __syncthreads();                             // B2: the tile's rows are staged (LDS writes drained; the loader waves pass through)
+        // B2: the tile's rows are staged.  NOT __syncthreads(): its workgroup-scope release also waits for vmcnt(0), i.e. for the global
+        // stores of the previous tile's rows -- a store round trip on the critical path of every tile.  Only the LDS writes must land.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (EPI == 0 || C) {
             // 32 rows x BN / 8 chunks of 16 bytes: whole rows leave in 16-byte pieces (BN / 8 lanes per row)
             constexpr int CH = BN / 8;
@@ -202,6 +208,9 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                     const int row = c / CH, chunk = c - row * CH;
                     if (m0 + row < M) {
                         const uint4 raw = *reinterpret_cast<const uint4*>(stage + (chunk >> 3) * 4096 + ws_off(row, chunk & 7));
+#ifdef GM3D_WS_PROBE_NO_STORE
+                        if (raw.x == 0x12345678u && raw.y == 0x9abcdef0u)
+#endif
                         *reinterpret_cast<uint4*>(C + (size_t)(m0 + row) * ldc + n0 + 8 * chunk) = raw;
                     }
                 }
