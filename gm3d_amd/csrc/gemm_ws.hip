@@ -46,28 +46,38 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 #undef GM3D_WS_CASE
 }
 
-// KT = K / 64; NW compute waves (32 output columns each: BN = 32 NW); NL loader waves; EPI 0: C = A.W^T (+ bias); EPI 3: max over
-// the tile's 32 rows (+ argmax, bias before or after the pool) into P / ARG, C rows optional (as gm3d_gemm_tn_bf16_pool).
-template <int KT, int NW, int NL, int EPI>
+// KT = K / 64; NW compute waves (32 output columns each: BN = 32 NW); NL loader waves; TM 32-row sub-tiles per ring slot (two: each
+// wave carries two independent accumulator chains -- the K / 16 MFMAs of ONE chain are dependent, ~64 cycles each -- and the two
+// barriers of an iteration are shared by 64 rows); EPI 0: C = A.W^T (+ bias); EPI 3: max over each sub-tile's 32 rows (+ argmax,
+// bias before or after the pool) into P / ARG, C rows optional (as gm3d_gemm_tn_bf16_pool).
+constexpr int ws_depth(int ppl, int tile, int stage) {
+    int d = 48 / ppl < 4 ? 48 / ppl : 4;                // vmcnt is a 6-bit counter
+    while (d > 1 && (d + 1) * tile + stage > 152 * 1024) --d;
+    return d;
+}
+
+template <int KT, int NW, int NL, int EPI, int TM>
 __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N,
                                                                      int lda, int ldw, int ldc, int tiles_n, bf16_t* __restrict__ P,
                                                                      uint8_t* __restrict__ ARG, int ldp, int bias_after_pool) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
-    constexpr int BN = 32 * NW;
-    constexpr int TILE = KT * 4096;                 // bytes of one [32][K] A tile: KT swizzled [32][64] images
-    constexpr int NP = 4 * KT;                      // 1-KiB LDS-DMA pieces per tile
-    constexpr int PPL = NP / NL;                    // pieces per loader wave and tile
-    constexpr int DEPTH = (48 / PPL) < 4 ? (48 / PPL) : 4;      // tiles in flight (vmcnt is a 6-bit counter); 2 measured the same
+    constexpr int BN = 32 * NW, NIMG = BN / 64 > 0 ? (BN + 63) / 64 : 1;
+    constexpr int HALF = KT * 4096;                 // bytes of one [32][K] sub-tile: KT swizzled [32][64] images
+    constexpr int TILE = TM * HALF;
+    constexpr int NP = TM * 4 * KT;                 // 1-KiB LDS-DMA pieces per slot
+    constexpr int PPL = NP / NL;                    // pieces per loader wave and slot
+    constexpr int STAGE = TM * NIMG * 4096;         // [32 TM][BN] bf16 as swizzled [32][64] images
+    constexpr int DEPTH = ws_depth(PPL, TILE, STAGE);          // slots in flight
     constexpr int NT = DEPTH + 1;                   // ring slots
-    static_assert(NP % NL == 0 && DEPTH >= 2, "loader split");
-    unsigned char* stage = wsm + NT * TILE;         // [32][BN] bf16 as BN / 64 swizzled [32][64] images
+    static_assert(NP % NL == 0 && PPL <= 48, "loader split");
+    unsigned char* stage = wsm + NT * TILE;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int per_xcd = gridDim.x >> 3;
     const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // column blocks of one row stream share an XCD's L2
     const int tile_n = logical % tiles_n, first = logical / tiles_n, stride = gridDim.x / tiles_n;
-    const int tiles_m = (M + 31) >> 5;
+    const int tiles_m = (M + 32 * TM - 1) / (32 * TM);
     const int nmine = first < tiles_m ? (tiles_m - first + stride - 1) / stride : 0;
     const int n0 = tile_n * BN;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)wsm;
@@ -76,12 +86,13 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
         // ------------------------------------------------------------------ loader wave(s): nothing but LDS-DMA and barriers
         const int lw = w - NW, prow = lane >> 3, pslot = lane & 7;
         auto issue = [&](int i) {
-            const int m0 = (first + i * stride) << 5;
+            const int m0 = (first + i * stride) * (32 * TM);
             const unsigned base = lds0 + (i % NT) * TILE;
 #pragma unroll
             for (int q = 0; q < PPL; ++q) {
-                const int p = lw * PPL + q, kt = p >> 2, row = 8 * (p & 3) + prow;
-                const int am = m0 + row < M ? m0 + row : M - 1;      // rows past M: clamped (their outputs are never stored)
+                const int p = lw * PPL + q, t = p / (4 * KT), pp = p - t * (4 * KT), kt = pp >> 2, row = 8 * (pp & 3) + prow;
+                const int gr = m0 + 32 * t + row;
+                const int am = gr < M ? gr : M - 1;                  // rows past M: clamped (their outputs are never stored)
 #ifdef GM3D_WS_PROBE_NO_LOAD
                 if (i < DEPTH)
 #endif
@@ -114,100 +125,118 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[q][e] = bias ? bias[n0 + 32 * w + 8 * q + 4 * hh + e] : 0.f;
+        for (int e = 0; e < 4; ++e) bq[q][e] = (EPI == 0 && bias) ? bias[n0 + 32 * w + 8 * q + 4 * hh + e] : 0.f;
+    const float bcol = (EPI == 3 && bias) ? bias[n0 + 32 * w + r] : 0.f;
     const bool bias_in_tile = EPI == 0 || !bias_after_pool;
     constexpr int CTHREADS = 64 * NW;
 
     for (int i = 0; i < nmine; ++i) {
-        const int m0 = (first + i * stride) << 5;
+        const int m0 = (first + i * stride) * (32 * TM);
         __builtin_amdgcn_s_barrier();                // B1
         const unsigned char* as = wsm + (i % NT) * TILE;
-        wf32x16 acc;
+        wf32x16 acc[TM];
 #pragma unroll
-        for (int g = 0; g < 16; ++g) acc[g] = 0.f;
+        for (int t = 0; t < TM; ++t)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[t][g] = 0.f;
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt) {
-            wbf16x8 fa[4];
+            wbf16x8 fa[TM][4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) fa[s] = *reinterpret_cast<const wbf16x8*>(as + kt * 4096 + ws_off(r, 2 * s + hh));
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) fa[t][s] = *reinterpret_cast<const wbf16x8*>(as + t * HALF + kt * 4096 + ws_off(r, 2 * s + hh));
             // EPI 0: the transposed tile (lane = row, registers = 4 x 4 consecutive columns: whole-row staging).  EPI 3: operands
             // swapped -> lane = COLUMN (lane & 31), registers = 16 of the 32 rows (8 (g >> 2) + 4 hh + (g & 3)), the other 16 in lane ^ 32:
             // the max over rows is 15 register maxima + one cross-lane step.  Same products, same k order: same bits.
 #ifndef GM3D_WS_PROBE_NO_MFMA
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc = EPI == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[s], wreg[kt][s], acc, 0, 0, 0)
-                               : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[s], acc, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < TM; ++t)
+                    acc[t] = EPI == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][s], wreg[kt][s], acc[t], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[t][s], acc[t], 0, 0, 0);
 #else
-            acc[0] += (float)fa[0][0] + (float)fa[1][1] + (float)fa[2][2] + (float)fa[3][3] + (float)wreg[kt][0][0];
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+                acc[t][0] += (float)fa[t][0][0] + (float)fa[t][1][1] + (float)fa[t][2][2] + (float)fa[t][3][3] + (float)wreg[kt][0][0];
 #endif
         }
         if (EPI == 3 && !C) __builtin_amdgcn_s_barrier();      // B2 (no rows to stage): tile i's slot may be refilled from here on
         if (EPI == 3) {
-            // acc[g]: row 8 (g >> 2) + 4 hh + (g & 3), column 32 w + r.  Rounded to bf16 (+ bias where it belongs before the rounding); ONE
-            // 32-bit key per element -- (order-preserving image of the bf16 value) << 16 | (31 - row) -- so that a plain unsigned max picks
-            // the largest value and, among equal values, the lowest row: the "first maximum wins" of gm3d_group_max_fwd (-0 counts as +0).
-            const float bcol = bias ? bias[n0 + 32 * w + r] : 0.f;          // (L1 hit after the first tile)
-            unsigned best = 0;
-            unsigned short rowbits[16];
+            // acc[t][g]: row 32 t + 8 (g >> 2) + 4 hh + (g & 3), column 32 w + r.  Rounded to bf16 (+ bias where it belongs before the
+            // rounding); ONE 32-bit key per element -- (order-preserving image of the bf16 value) << 16 | (31 - row) -- so that a plain
+            // unsigned max picks the largest value and, among equal values, the lowest row: the "first maximum wins" of
+            // gm3d_group_max_fwd (-0 counts as +0).
+            unsigned short rowbits[TM][16];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const bf16_t o = (bf16_t)(acc[g] + (bias_in_tile ? bcol : 0.f));
-                rowbits[g] = __builtin_bit_cast(unsigned short, o);
-                unsigned u = (unsigned)rowbits[g] << 16;
-                u = u == 0x80000000u ? 0u : u;
-                const unsigned k = (u ^ (unsigned)(((int)u >> 31) | (int)0x80000000)) & 0xffff0000u;
-                const unsigned key = k | (unsigned)(31 - (8 * (g >> 2) + 4 * hh + (g & 3)));
-                best = key > best ? key : best;
-            }
-            {   // the other 16 rows of this column sit in lane ^ 32
-                const unsigned other = (unsigned)__shfl_xor((int)best, 32);
-                best = other > best ? other : best;
-            }
-            if (hh == 0 && m0 < M) {
-                const unsigned k = best & 0xffff0000u;
-                const unsigned u = (k & 0x80000000u) ? (k & 0x7fff0000u) : (~k & 0xffff0000u);
-                float v = __builtin_bit_cast(float, u);
-                if (bias_after_pool) v += bcol;
-                const size_t o = (size_t)(m0 >> 5) * ldp + n0 + 32 * w + r;
-                P[o] = (bf16_t)v;
-                ARG[o] = (uint8_t)(31u - (best & 0xffu));
+            for (int t = 0; t < TM; ++t) {
+                unsigned best = 0;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const bf16_t o = (bf16_t)(acc[t][g] + (bias_in_tile ? bcol : 0.f));
+                    rowbits[t][g] = __builtin_bit_cast(unsigned short, o);
+                    unsigned u = (unsigned)rowbits[t][g] << 16;
+                    u = u == 0x80000000u ? 0u : u;
+                    const unsigned k = (u ^ (unsigned)(((int)u >> 31) | (int)0x80000000)) & 0xffff0000u;
+                    const unsigned key = k | (unsigned)(31 - (8 * (g >> 2) + 4 * hh + (g & 3)));
+                    best = key > best ? key : best;
+                }
+                {   // the other 16 rows of this column sit in lane ^ 32
+                    const unsigned other = (unsigned)__shfl_xor((int)best, 32);
+                    best = other > best ? other : best;
+                }
+                if (hh == 0 && m0 + 32 * t < M) {
+                    const unsigned k = best & 0xffff0000u;
+                    const unsigned u = (k & 0x80000000u) ? (k & 0x7fff0000u) : (~k & 0xffff0000u);
+                    float v = __builtin_bit_cast(float, u);
+                    if (bias_after_pool) v += bcol;
+                    const size_t o = (size_t)((m0 >> 5) + t) * ldp + n0 + 32 * w + r;
+                    P[o] = (bf16_t)v;
+                    ARG[o] = (uint8_t)(31u - (best & 0xffu));
+                }
             }
             if (!C) continue;                        // no rows wanted (second_conv.3): nothing is staged
-            // rows wanted (first_conv.3): this lane's 16 values of column 32 w + r into the staging image, 2 bytes at a time
-            unsigned char* img = stage + ((32 * w) >> 6) * 4096;
+            // rows wanted (first_conv.3): this lane's 16 values of column 32 w + r into the staging images, 2 bytes at a time
             const int ch = (((32 * w) & 63) + r) >> 3, sub = 2 * (r & 7);
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int row = 8 * (g >> 2) + 4 * hh + (g & 3);
-                *reinterpret_cast<unsigned short*>(img + ws_off(row, ch) + sub) = rowbits[g];
+            for (int t = 0; t < TM; ++t) {
+                unsigned char* img = stage + (t * NIMG + ((32 * w) >> 6)) * 4096;
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int row = 8 * (g >> 2) + 4 * hh + (g & 3);
+                    *reinterpret_cast<unsigned short*>(img + ws_off(row, ch) + sub) = rowbits[t][g];
+                }
             }
         } else {
-            // acc[4 q + e]: row r, column 32 w + 8 q + 4 hh + e, rounded to bf16 (+ bias) into the staging images (image = 64 columns)
-            unsigned char* img = stage + ((32 * w) >> 6) * 4096;
+            // acc[t][4 q + e]: row 32 t + r, column 32 w + 8 q + 4 hh + e, rounded to bf16 (+ bias) into the staging images
             const int cbase = ((32 * w) & 63) >> 3;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                wbf16x4 pk;
+            for (int t = 0; t < TM; ++t) {
+                unsigned char* img = stage + (t * NIMG + ((32 * w) >> 6)) * 4096;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[4 * q + e] + bq[q][e]);
-                *reinterpret_cast<wbf16x4*>(img + ws_off(r, cbase + q) + 8 * hh) = pk;
+                for (int q = 0; q < 4; ++q) {
+                    wbf16x4 pk;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[t][4 * q + e] + bq[q][e]);
+                    *reinterpret_cast<wbf16x4*>(img + ws_off(r, cbase + q) + 8 * hh) = pk;
+                }
             }
         }
         // B2: the tile's rows are staged.  NOT __syncthreads(): its workgroup-scope release also waits for vmcnt(0), i.e. for the global
-        // stores of the previous tile's rows -- a store round trip on the critical path of every tile.  Only the LDS writes must land.
+        // stores of the previous tile's rows.  Only the LDS writes must land.
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (EPI == 0 || C) {
-            // 32 rows x BN / 8 chunks of 16 bytes: whole rows leave in 16-byte pieces (BN / 8 lanes per row)
+        {
+            // 32 TM rows x BN / 8 chunks of 16 bytes: whole rows leave in 16-byte pieces (BN / 8 lanes per row)
             constexpr int CH = BN / 8;
 #pragma unroll
-            for (int c0 = 0; c0 < 32 * CH; c0 += CTHREADS) {
+            for (int c0 = 0; c0 < 32 * TM * CH; c0 += CTHREADS) {
                 const int c = c0 + tid;
-                if (c < 32 * CH) {
+                if (c < 32 * TM * CH) {
                     const int row = c / CH, chunk = c - row * CH;
                     if (m0 + row < M) {
-                        const uint4 raw = *reinterpret_cast<const uint4*>(stage + (chunk >> 3) * 4096 + ws_off(row, chunk & 7));
+                        const uint4 raw = *reinterpret_cast<const uint4*>(stage + ((row >> 5) * NIMG + (chunk >> 3)) * 4096 + ws_off(row & 31, chunk & 7));
 #ifdef GM3D_WS_PROBE_NO_STORE
                         if (raw.x == 0x12345678u && raw.y == 0x9abcdef0u)
 #endif
@@ -229,6 +258,8 @@ extern "C" int gm3d_gemm_ws_set_occupancy(int wg_per_cu) {
     return GM3D_OK;
 }
 
+using gm3d::ws_depth;
+
 static int ws_grid(int tiles_m, int tiles_n, size_t lds) {
     long long want = (long long)tiles_m * tiles_n;
     const int cap = (WS_WG_PER_CU == 2 && 2 * lds <= 160 * 1024) ? 512 : 256;
@@ -246,33 +277,35 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
     if (K % 64 || K > 512 || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
     if (((size_t)A | (size_t)W | (size_t)C) & 15) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
-    const int tiles_m = (M + 31) / 32;
     hipStream_t st = (hipStream_t)stream;
-#define GM3D_WS_LAUNCH(KT, NW, NL, EPI)                                                                                   \
+#define GM3D_WS_LAUNCH(KT, NW, NL, EPI, TM)                                                                               \
     {                                                                                                                    \
-        constexpr int PPL_ = 4 * KT / NL, DEPTH_ = (48 / PPL_) < 4 ? (48 / PPL_) : 4;                                    \
-        const size_t lds = (size_t)(DEPTH_ + 1) * KT * 4096 + (size_t)64 * 32 * NW;                                      \
-        const int tiles_n = N / (32 * NW), grid = ws_grid(tiles_m, tiles_n, lds);                                             \
+        constexpr int TILE_ = TM * KT * 4096, STAGE_ = TM * ((32 * NW + 63) / 64) * 4096;                                \
+        constexpr int DEPTH_ = ws_depth(TM * 4 * KT / NL, TILE_, STAGE_);                                                \
+        const size_t lds = (size_t)(DEPTH_ + 1) * TILE_ + STAGE_;                                                        \
+        const int tiles_m = (M + 32 * TM - 1) / (32 * TM);                                                               \
+        const int tiles_n = N / (32 * NW), grid = ws_grid(tiles_m, tiles_n, lds);                                        \
         static LdsAttr attr;                                                                                             \
-        if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI>, lds)) return GM3D_ELAUNCH;                     \
-        hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI>), dim3(grid), dim3(64 * (NW + NL)), lds, st, (const bf16_t*)A, \
-                           (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp,       \
+        if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>, lds)) return GM3D_ELAUNCH;                 \
+        hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>), dim3(grid), dim3(64 * (NW + NL)), lds, st,          \
+                           (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp, \
                            bias_after_pool);                                                                             \
         GM3D_CHECK_LAUNCH();                                                                                             \
         return GM3D_OK;                                                                                                  \
     }
     // the shapes of the mini-PointNet (models_mae_learn_loss.py:872-883) and of its backward; anything else: EUNSUPPORTED
     if (P) {
-        if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 3)          // first_conv.3 + max-pool
-        if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 3)          // second_conv.3 + max-pool (two column blocks of 192)
+        // (TM = 2 -- two sub-tiles per slot, two accumulator chains per wave -- measured no faster on any shape: TM = 1 everywhere)
+        if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 3, 1)       // first_conv.3 + max-pool
+        if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 3, 1)       // second_conv.3 + max-pool (two column blocks of 192)
         return GM3D_EUNSUPPORTED;
     }
-    if (K == 256 && N == 512) GM3D_WS_LAUNCH(4, 8, 1, 0)              // second_conv.0 on the local half (two column blocks)
-    if (K == 512 && N == 256) GM3D_WS_LAUNCH(8, 4, 2, 0)              // its input gradient (128 VGPRs of W per wave: 6 waves per CU)
-    if (K == 384 && N == 512) GM3D_WS_LAUNCH(6, 8, 2, 0)              // second_conv.3's input gradient
-    if (K == 256 && N == 128) GM3D_WS_LAUNCH(4, 4, 1, 0)              // first_conv.3's input gradient
-    if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 0)
-    if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 0)
+    if (K == 256 && N == 512) GM3D_WS_LAUNCH(4, 8, 1, 0, 1)           // second_conv.0 on the local half (two column blocks)
+    if (K == 512 && N == 256) GM3D_WS_LAUNCH(8, 4, 2, 0, 1)           // its input gradient (128 VGPRs of W per wave: 6 waves per CU)
+    if (K == 384 && N == 512) GM3D_WS_LAUNCH(6, 8, 2, 0, 1)           // second_conv.3's input gradient
+    if (K == 256 && N == 128) GM3D_WS_LAUNCH(4, 4, 1, 0, 1)           // first_conv.3's input gradient
+    if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 0, 1)
+    if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 0, 1)
 #undef GM3D_WS_LAUNCH
     return GM3D_EUNSUPPORTED;
 }

@@ -154,8 +154,10 @@ def linear_gelu(x, w, bias, f_out=None, g_out=None):
 
 USE_WS = True             # tall products (M >= 32768) of the mini-PointNet shapes on the weight-stationary kernel (csrc/gemm_ws.hip):
 #                           40 / 104 / 55 / 104 / 43 us against 53 / 142 / 76 / 112 / 47 on the tiled kernels (r03 table), -0.13 ms per step
-USE_WS_POOL = False       # its max-pool epilogue (a DPP reduction over the 32 rows of the accumulator tile) is correct but costs ~450
-#                           VALU instructions per wave and tile: 102 / 218 us against 77 / 143 on csrc/gemm_dma.hip (tools/pool_kbench.py)
+USE_WS_POOL = True        # ... and conv + max-pool (the product computed non-transposed for these tiles: lane = column, so the pool is a
+#                           register max + one cross-lane step): 80 / 138 / 55 us against 80 / 144 / 57 on csrc/gemm_dma.hip, +0.4 % in the
+#                           step (same-box A/B 7.857 vs 7.890 ms).  (A first form -- DPP reduction over the rows of the transposed tile, ~700
+#                           VALU instructions per wave and tile -- took 102 / 218 us.)
 
 
 def ws_supported(x, w, pool=False):
