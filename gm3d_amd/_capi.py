@@ -102,6 +102,8 @@ SIGNATURES = {
     "gm3d_pn_layer1_bwd_stats": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_colsum_finish_f64": [_vp, _i, _i, _i, _vp, _vp],
     "gm3d_colsum_partial": [_vp, _i, _i, _vp, _i, _vp],
+    "gm3d_gather_inverse": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "gm3d_gather_rows_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gm3d_add_ln_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_add_ln_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "gm3d_colsum_partial_w": [_vp, _vp, _i, _i, _vp, _i, _vp],

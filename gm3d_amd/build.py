@@ -29,6 +29,7 @@ SOURCES = {
     "gemm_ring.hip": [],
     "gemm_dma.hip": [],
     "gemm_ws.hip": [],
+    "gather.hip": [],
     "attention_masked.hip": [],
 }
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]

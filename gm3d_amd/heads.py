@@ -177,6 +177,45 @@ class AddLayerNormFn(torch.autograd.Function):
                     gb[C:2 * C].to(wdt), None, None)
 
 
+class TakeRowsFn(torch.autograd.Function):
+    """y[b, j] = x[b, ids[b, j]] for ids (B,J) int64 that may REPEAT a source row (a token that is a member of several groups; the
+    three nearest coarse tokens of the token propagation).  Forward: torch.gather.  Backward: csrc/gather.hip -- the inverse lists of
+    ids in ascending j, then every source row sums its readers' gradients in that order: deterministic, unlike the colliding float
+    atomics of PyTorch's gather backward."""
+
+    @staticmethod
+    def forward(ctx, x, ids):
+        B, S, C = x.shape
+        ids = ids.contiguous()
+        ctx.save_for_backward(ids)
+        ctx.S, ctx.xdt = S, x.dtype
+        return torch.gather(x, 1, ids.unsqueeze(-1).expand(-1, -1, C))
+
+    @staticmethod
+    def backward(ctx, dy):
+        (ids,) = ctx.saved_tensors
+        B, J = ids.shape
+        S, C = ctx.S, dy.shape[-1]
+        dy = dy.contiguous()
+        if dy.dtype not in _DT:
+            dy = dy.float()
+        off = torch.empty(B, S + 1, dtype=torch.int32, device=dy.device)
+        lst = torch.empty(B, J, dtype=torch.int32, device=dy.device)
+        _launch("gm3d_gather_inverse", {"B": B, "J": J, "S": S}, lib.gm3d_gather_inverse, _ptr(ids), B, J, S, _ptr(off), _ptr(lst), _stream())
+        dx = torch.empty(B, S, C, dtype=dy.dtype, device=dy.device)
+        _launch("gm3d_gather_rows_bwd", {"B": B, "J": J, "S": S, "C": C, "dtype": str(dy.dtype)}, lib.gm3d_gather_rows_bwd, _ptr(dy), _ptr(off),
+                _ptr(lst), _ptr(dx), B, J, S, C, _DT[dy.dtype], _stream())
+        return dx.to(ctx.xdt), None
+
+
+def take_rows(x, ids):
+    """x (B,S,C) gathered along dim 1 by ids (B,J) with a deterministic backward (GPU, C % 8 == 0); else models_mae_learn_loss.take."""
+    if x.is_cuda and x.dim() == 3 and x.shape[-1] % 8 == 0 and ids.dtype == torch.int64 and x.shape[1] <= 4096 and ids.shape[1] <= 16384:
+        return TakeRowsFn.apply(x, ids)
+    from .models_mae_learn_loss import take
+    return take(x, ids)
+
+
 class ResidualTailFn(torch.autograd.Function):
     """out = x + rowscale[sample] * (y + ybias): the last residual sum of a block stack (no LayerNorm behind it) on the same
     kernels as AddLayerNormFn -- the gradient of ybias is our own column sum (PyTorch's reduction over B*T rows is not

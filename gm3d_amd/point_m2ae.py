@@ -263,7 +263,8 @@ class TokenPropagation(nn.Module):
             dist, idx = ops.knn(xyz_coarse, xyz_fine, 3)                   # (B,N,3): Euclidean distances, ascending
             w = 1.0 / (dist * dist + 1e-8)
             w = w / w.sum(dim=-1, keepdim=True)
-        near = M.take(tok_coarse, idx.reshape(B, N * 3)).view(B, N, 3, -1)
+        from . import heads
+        near = heads.take_rows(tok_coarse, idx.reshape(B, N * 3)).view(B, N, 3, -1)     # (deterministic backward: a coarse token has many readers)
         interp = (near * w.unsqueeze(-1).to(near.dtype)).sum(dim=2)
         y = torch.cat([tok_fine, interp.to(tok_fine.dtype)], dim=-1).reshape(B * N, -1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
@@ -335,7 +336,8 @@ class PointM2AE(nn.Module):
                     tok = self.token_embed[0](neighborhoods[0])
             else:
                 B, G, k = idxs[i].shape
-                tok = self.token_embed[i](M.take(prev, idxs[i].reshape(B, G * k)).view(B, G, k, -1))
+                from . import heads
+                tok = self.token_embed[i](heads.take_rows(prev, idxs[i].reshape(B, G * k)).view(B, G, k, -1))
             vis = ~masks[i]
             with torch.no_grad():       # == pack_mask(~(vis_i & vis_j) | radius_mask(centres)), one launch
                 bits = ops.radius_mask_bits(centers[i], vis, self.local_radius[i])

@@ -477,6 +477,13 @@ int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
  * (2 HD + 16) bytes, the backward 4*32*ceil(T/32) * (2 HD + 16) + 8*32*ceil(T/32), at most 160 KiB -- i.e. T <= 512 for HD <= 32
  * and, for HD = 64, T <= 480 forward / T <= 256 backward (GM3D_EUNSUPPORTED beyond).  With mask = NULL and HD = 64 these are also
  * the attention of the Point-MAE models for more than 128 tokens (cfgs/config_3.yaml: 256 groups). */
+/* Deterministic backward of a row gather with repeated indices (the hierarchical model's member / 3-NN token gathers: PyTorch's
+ * gather backward scatter-adds with colliding float atomics).  gm3d_gather_inverse: idx (B,J) int64 with values in [0,S) -> the
+ * inverse lists in CSR form, off (B,S+1) int32 and list (B,J) int32, every list in ascending j (S <= 4096, J <= 16384);
+ * gm3d_gather_rows_bwd: dx (B,S,C) = sum over each source's list of dy (B,J,C) rows, in list order (fp32 accumulation, C % 8 == 0). */
+int gm3d_gather_inverse(const long long *idx, int B, int J, int S, int *off, int *list, gm3d_stream_t stream);
+int gm3d_gather_rows_bwd(const void *dy, const int *off, const int *list, void *dx, int B, int J, int S, int C, int dtype,
+                         gm3d_stream_t stream);
 /* The bitset mask of one level of the hierarchical encoder: bits (B,G,ceil(G/32)), bit j of row i set iff token i or token j is
  * not visible (vis (B,G) bytes, NULL = all visible) or their centres (B,G,3) are >= radius apart (radius <= 0: no radius test). */
 int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float radius, int B, int G, unsigned *bits,

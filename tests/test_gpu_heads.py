@@ -183,3 +183,29 @@ def test_patch_chamfer_loss_equals_the_op_chain(dtype, B, M):
     tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
     assert float((got_g.float() - pix.grad.float()).abs().max()) <= tol * scale
     assert float(got_g[:, :L - M].abs().max()) == 0.0 if M < L else True
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_take_rows_deterministic_backward(dtype):
+    """heads.take_rows: gather with repeated indices; the backward (csrc/gather.hip: inverse lists in ascending j, then an ordered sum
+    per source row) equals an fp64 index_add of the same gradients within one rounding and is BIT-IDENTICAL from run to run (PyTorch's
+    scatter-add with colliding atomics is not), including rows nobody reads (zeros)."""
+    from gm3d_amd import heads
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for B, S, J, C in ((5, 64, 768, 384), (3, 512, 2048, 96), (2, 256, 512, 192), (1, 7, 40, 8)):
+        x = torch.randn(B, S, C, device="cuda", generator=g).to(dtype).requires_grad_(True)
+        ids = torch.randint(0, S - 1, (B, J), device="cuda", generator=g)            # row S-1 is never read
+        dy = torch.randn(B, J, C, device="cuda", generator=g).to(dtype)
+        y = heads.take_rows(x, ids)
+        assert torch.equal(y, torch.gather(x, 1, ids.unsqueeze(-1).expand(-1, -1, C)))
+        y.backward(dy)
+        first = x.grad.clone()
+        ref = torch.zeros(B, S, C, device="cuda", dtype=torch.float64)
+        ref.scatter_add_(1, ids.unsqueeze(-1).expand(-1, -1, C), dy.double())
+        tol = 1e-6 if dtype == torch.float32 else 1e-2
+        assert float((first.double() - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1.0)
+        assert bool((first[:, S - 1] == 0).all())
+        for _ in range(3):
+            x.grad = None
+            heads.take_rows(x, ids).backward(dy)
+            assert torch.equal(x.grad, first)
