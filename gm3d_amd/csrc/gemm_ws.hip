@@ -50,6 +50,20 @@ __device__ __forceinline__ void ws_wait_vm(int n) {
 // wave carries two independent accumulator chains -- the K / 16 MFMAs of ONE chain are dependent, ~64 cycles each -- and the two
 // barriers of an iteration are shared by 64 rows); EPI 0: C = A.W^T (+ bias); EPI 3: max over each sub-tile's 32 rows (+ argmax,
 // bias before or after the pool) into P / ARG, C rows optional (as gm3d_gemm_tn_bf16_pool).
+// EPI 4 / 5 (the second BatchNorm of the mini-PointNet around second_conv.0, 32-row tiles = one group each; T (M / 32, N) is the per-group
+// term of the split concat product): 4 = eval-mode BatchNorm + ReLU applied to the bf16-rounded product in the epilogue,
+// C = act((bf16(A.W^T) + T[group]) * scale + shift) -- the arithmetic of bn_bcast_apply_relu_kernel on the stored product, bit for bit;
+// 5 = train mode: C = bf16(A.W^T) as EPI 0, plus this workgroup's column sums of y = C + T[group] and y^2 (bn_bcast_stats_kernel's
+// statistics) -> partial[first][0 | 1][N], one row per workgroup of a column block, accumulated in a fixed order.
+struct WsBn {
+    const bf16_t* T;
+    const float* scale;
+    const float* shift;
+    float* partial;
+    int ldt;
+    float slope;
+};
+
 constexpr int ws_depth(int ppl, int tile, int stage) {
     int d = 48 / ppl < 4 ? 48 / ppl : 4;                // vmcnt is a 6-bit counter
     while (d > 1 && (d + 1) * tile + stage > 152 * 1024) --d;
@@ -60,7 +74,7 @@ template <int KT, int NW, int NL, int EPI, int TM>
 __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N,
                                                                      int lda, int ldw, int ldc, int tiles_n, bf16_t* __restrict__ P,
-                                                                     uint8_t* __restrict__ ARG, int ldp, int bias_after_pool) {
+                                                                     uint8_t* __restrict__ ARG, int ldp, int bias_after_pool, WsBn bn) {
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     constexpr int BN = 32 * NW, NIMG = BN / 64 > 0 ? (BN + 63) / 64 : 1;
     constexpr int HALF = KT * 4096;                 // bytes of one [32][K] sub-tile: KT swizzled [32][64] images
@@ -125,13 +139,33 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) bq[q][e] = (EPI == 0 && bias) ? bias[n0 + 32 * w + 8 * q + 4 * hh + e] : 0.f;
+        for (int e = 0; e < 4; ++e) bq[q][e] = (EPI != 3 && bias) ? bias[n0 + 32 * w + 8 * q + 4 * hh + e] : 0.f;
     const float bcol = (EPI == 3 && bias) ? bias[n0 + 32 * w + r] : 0.f;
-    const bool bias_in_tile = EPI == 0 || !bias_after_pool;
+    const bool bias_in_tile = EPI != 3 || !bias_after_pool;
+    // EPI 4: this lane's 16 columns of (scale, shift).  EPI 5: their running sums of y and y^2 over this workgroup's tiles.
+    float bn_a[4][4], bn_b[4][4];
+    if (EPI == 4 || EPI == 5) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = n0 + 32 * w + 8 * q + 4 * hh + e;
+                bn_a[q][e] = EPI == 4 ? bn.scale[col] : 0.f;
+                bn_b[q][e] = EPI == 4 ? bn.shift[col] : 0.f;
+            }
+    }
     constexpr int CTHREADS = 64 * NW;
 
     for (int i = 0; i < nmine; ++i) {
         const int m0 = (first + i * stride) * (32 * TM);
+        wbf16x4 tq[TM][4];
+        if (EPI == 4 || EPI == 5) {                  // the groups' row of T: in flight while the tile is multiplied
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    tq[t][q] = *reinterpret_cast<const wbf16x4*>(bn.T + (size_t)((m0 >> 5) + t) * bn.ldt + n0 + 32 * w + 8 * q + 4 * hh);
+        }
         __builtin_amdgcn_s_barrier();                // B1
         const unsigned char* as = wsm + (i % NT) * TILE;
         wf32x16 acc[TM];
@@ -218,7 +252,18 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                 for (int q = 0; q < 4; ++q) {
                     wbf16x4 pk;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) pk[e] = (bf16_t)(acc[t][4 * q + e] + bq[q][e]);
+                    for (int e = 0; e < 4; ++e) {
+                        pk[e] = (bf16_t)(acc[t][4 * q + e] + bq[q][e]);
+                        if (EPI == 4) {
+                            const float h = ((float)pk[e] + (float)tq[t][q][e]) * bn_a[q][e] + bn_b[q][e];
+                            pk[e] = (bf16_t)(h > 0.f ? h : bn.slope * h);
+                        }
+                        if (EPI == 5) {
+                            const float y = (float)pk[e] + (float)tq[t][q][e];
+                            bn_a[q][e] += y;
+                            bn_b[q][e] += y * y;
+                        }
+                    }
                     *reinterpret_cast<wbf16x4*>(img + ws_off(r, cbase + q) + 8 * hh) = pk;
                 }
             }
@@ -246,6 +291,24 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             }
         }
     }
+    if (EPI == 5) {
+        // the 32 lanes of a half (same hh: same 16 columns, 32 different rows) fold their sums in a fixed butterfly order
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int m = 1; m < 32; m <<= 1) {
+                    bn_a[q][e] += __shfl_xor(bn_a[q][e], m);
+                    bn_b[q][e] += __shfl_xor(bn_b[q][e], m);
+                }
+                if (r == 0) {
+                    const int col = n0 + 32 * w + 8 * q + 4 * hh + e;
+                    bn.partial[(size_t)first * 2 * N + col] = bn_a[q][e];
+                    bn.partial[(size_t)first * 2 * N + N + col] = bn_b[q][e];
+                }
+            }
+    }
 }
 
 }  // namespace gm3d
@@ -270,7 +333,7 @@ static int ws_grid(int tiles_m, int tiles_n, size_t lds) {
 }
 
 static int ws_launch(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* ARG, int M, int N, int K, int lda,
-                     int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream) {
+                     int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream, int bn_mode = 0, gm3d::WsBn bn = gm3d::WsBn()) {
     using namespace gm3d;
     if (!A || !W || (!C && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp % 8 || ldp < N || ((size_t)ARG & 7) || ((size_t)P & 15))) return GM3D_EINVAL;
@@ -289,7 +352,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>, lds)) return GM3D_ELAUNCH;                 \
         hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>), dim3(grid), dim3(64 * (NW + NL)), lds, st,          \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp, \
-                           bias_after_pool);                                                                             \
+                           bias_after_pool, bn);                                                                         \
         GM3D_CHECK_LAUNCH();                                                                                             \
         return GM3D_OK;                                                                                                  \
     }
@@ -298,6 +361,12 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         // (TM = 2 -- two sub-tiles per slot, two accumulator chains per wave -- measured no faster on any shape: TM = 1 everywhere)
         if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 3, 1)       // first_conv.3 + max-pool
         if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 3, 1)       // second_conv.3 + max-pool (two column blocks of 192)
+        return GM3D_EUNSUPPORTED;
+    }
+    if (bn_mode) {                                                    // second_conv.0 with the BatchNorm that follows it (EPI 4 / 5)
+        if (M % 32 || !bn.T || bn.ldt % 4 || bn.ldt < N || ((size_t)bn.T & 7)) return GM3D_EINVAL;
+        if (K == 256 && N == 512 && bn_mode == 4) GM3D_WS_LAUNCH(4, 8, 1, 4, 1)
+        if (K == 256 && N == 512 && bn_mode == 5) GM3D_WS_LAUNCH(4, 8, 1, 5, 1)
         return GM3D_EUNSUPPORTED;
     }
     if (K == 256 && N == 512) GM3D_WS_LAUNCH(4, 8, 1, 0, 1)           // second_conv.0 on the local half (two column blocks)
@@ -320,6 +389,37 @@ extern "C" int gm3d_gemm_tn_bf16_ws_pool(const void* A, const void* W, const flo
                                          int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream) {
     if (!P || !arg) return GM3D_EINVAL;
     return ws_launch(A, W, bias, C, P, arg, M, N, K, lda, ldw, ldc, ldp, bias_after_pool, stream);
+}
+
+// C = act((bf16(A.W^T) + T[row / 32]) * scale + shift), act(h) = h > 0 ? h : slope h: the product, the per-group term of the split
+// concat and an eval-mode BatchNorm + ReLU in one launch (T (M / 32, N) bf16, scale / shift (N) f32).  M % 32 == 0.
+extern "C" int gm3d_gemm_tn_bf16_ws_bn_apply(const void* A, const void* W, const void* T, const float* scale, const float* shift, float slope,
+                                             void* C, int M, int N, int K, int lda, int ldw, int ldt, int ldc, gm3d_stream_t stream) {
+    if (!C || !T || !scale || !shift) return GM3D_EINVAL;
+    gm3d::WsBn bn;
+    bn.T = (const gm3d::bf16_t*)T; bn.scale = scale; bn.shift = shift; bn.partial = nullptr; bn.ldt = ldt; bn.slope = slope;
+    return ws_launch(A, W, nullptr, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream, 4, bn);
+}
+
+// C = bf16(A.W^T) and, per workgroup, the column sums of y = C + T[row / 32] and of y^2: partial (gm3d_gemm_ws_stats_rows, 2 N) f32,
+// every row written (no memset), to be summed over the rows in order (gm3d_colsum_finish) -- the train-mode statistics of the
+// BatchNorm behind the product without another pass over it.
+extern "C" int gm3d_gemm_tn_bf16_ws_bn_stats(const void* A, const void* W, const void* T, void* C, float* partial, int M, int N, int K,
+                                             int lda, int ldw, int ldt, int ldc, gm3d_stream_t stream) {
+    if (!C || !T || !partial) return GM3D_EINVAL;
+    gm3d::WsBn bn;
+    bn.T = (const gm3d::bf16_t*)T; bn.scale = nullptr; bn.shift = nullptr; bn.partial = partial; bn.ldt = ldt; bn.slope = 0.f;
+    return ws_launch(A, W, nullptr, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream, 5, bn);
+}
+
+// rows of gm3d_gemm_tn_bf16_ws_bn_stats' partial buffer for this shape (0: unsupported)
+extern "C" int gm3d_gemm_ws_stats_rows(int M, int N, int K) {
+    if (!(K == 256 && N == 512) || M % 32 || M < 32) return 0;
+    constexpr int KT = 4, NW = 8, NL = 1;
+    constexpr int TILE_ = KT * 4096, STAGE_ = ((32 * NW + 63) / 64) * 4096;
+    const size_t lds = (size_t)(ws_depth(4 * KT / NL, TILE_, STAGE_) + 1) * TILE_ + STAGE_;
+    const int tiles_n = N / (32 * NW);
+    return ws_grid(M / 32, tiles_n, lds) / tiles_n;
 }
 
 // 1 when gm3d_gemm_tn_bf16_ws[_pool] has an instantiation for (N, K)

@@ -141,21 +141,29 @@ class EmbedFn(torch.autograd.Function):
         W3 = weight_cache.get(w3, adt).reshape(C3, 2 * C2)
         W3g, W3l = W3[:, :C2], W3[:, C2:]
         t = gemm.mm(fg, W3g, _c32(b3))
-        y0 = gemm.mm(f, W3l)
-        st = None
+        vis = meta.get("vis_ids")
+        # the product with the BatchNorm behind it in its epilogue (csrc/gemm_ws.hip EPI 4 / 5): train mode -> its statistics come
+        # out of the product's launch (no second pass over the (rows, 512) tensor); eval mode (the EMA teacher) -> BN + ReLU applied
+        # there, the product itself never reaches HBM
+        fuse_bn = K == 32 and gemm.ws_bn_supported(f, W3l, t)
+        y0 = st = None
         if training:
-            nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
-            part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
-            _launch("gm3d_bn_bcast_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
-                    _ptr(t), BG, K, C3, _ptr(part), dt_id, _stream())
-            st = _finish(part, nrows, 2 * C3)
+            if fuse_bn:
+                y0, part = gemm.linear_ws_bn_stats(f, W3l, t)
+                st = _finish(part, part.shape[0], 2 * C3)
+            else:
+                y0 = gemm.mm(f, W3l)
+                nrows = lib.gm3d_embed_partial_rows(1, BG, C3)
+                part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
+                _launch("gm3d_bn_bcast_stats", {"G": BG, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_stats, _ptr(y0),
+                        _ptr(t), BG, K, C3, _ptr(part), dt_id, _stream())
+                st = _finish(part, nrows, 2 * C3)
         g2c, be2c = _c32(g2), _c32(be2)
         scale2, shift2 = torch.empty(C3, **f32), torch.empty(C3, **f32)
         mean2, rstd2 = torch.empty(C3, **f32), torch.empty(C3, **f32)
         _launch("gm3d_bn_finalize", {"C": C3}, lib.gm3d_bn_finalize, _ptr(st), float(R), _ptr(g2c), _ptr(be2c), eps, mom,
                 _ptr(rm2), _ptr(rv2), _ptr(nbt2), _ptr(scale2), _ptr(shift2), _ptr(mean2), _ptr(rstd2), C3, int(training),
                 _stream())
-        vis = meta.get("vis_ids")
         sel = inv = None
         BGs, Gs = BG, G                       # groups that go through conv4
         if vis is not None:
@@ -167,9 +175,14 @@ class EmbedFn(torch.autograd.Function):
             inv = torch.empty(BG, dtype=torch.int32, device=dev)
             _launch("gm3d_group_select_maps", {"B": B, "V": Gs, "G": G}, lib.gm3d_group_select_maps, _ptr(vis), vis.stride(0), B,
                     Gs, G, _ptr(sel), _ptr(inv), _stream())
-        a2 = torch.empty(BGs * K, C3, dtype=adt, device=dev)
-        _launch("gm3d_bn_bcast_apply_relu", {"G": BGs, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu_sel,
-                _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), _ptr(sel), BGs, K, C3, 0.0, dt_id, _stream())
+        if not training and fuse_bn and vis is None:
+            a2 = gemm.linear_ws_bn_apply(f, W3l, t, scale2, shift2)
+        else:
+            if y0 is None:
+                y0 = gemm.mm(f, W3l)
+            a2 = torch.empty(BGs * K, C3, dtype=adt, device=dev)
+            _launch("gm3d_bn_bcast_apply_relu", {"G": BGs, "K": K, "C": C3, "dtype": str(adt)}, lib.gm3d_bn_bcast_apply_relu_sel,
+                    _ptr(y0), _ptr(t), _ptr(scale2), _ptr(shift2), _ptr(a2), _ptr(sel), BGs, K, C3, 0.0, dt_id, _stream())
         # ---- conv4 + max-pool ----
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         b4f = _c32(b4)

@@ -413,6 +413,18 @@ int gm3d_gemm_tn_bf16_ws(const void *A, const void *W, const float *bias, void *
 int gm3d_gemm_tn_bf16_ws_pool(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N, int K,
                               int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
 int gm3d_gemm_ws_supported(int N, int K, int pool);
+/* second_conv.0 (256 -> 512 on the local half of the split concat, models_mae_learn_loss.py:880) together with the BatchNorm1d(512)
+ * + ReLU behind it (:881), T (M / 32, N) bf16 being the per-group term (global feature @ W_g^T + bias), M % 32 == 0:
+ *   _bn_apply  eval-mode BatchNorm (the EMA teacher): C = act((bf16(A.W^T) + T[row / 32]) * scale + shift), act(h) = h > 0 ? h : slope h
+ *              -- bit-identical to gm3d_gemm_tn_bf16_ws followed by gm3d_bn_bcast_apply_relu, the product never reaches HBM;
+ *   _bn_stats  train mode: C = bf16(A.W^T) plus per-workgroup column sums of y = C + T[row / 32] and y^2 into partial
+ *              (gm3d_gemm_ws_stats_rows(M, N, K) rows x 2 N f32, every row written): what gm3d_bn_bcast_stats would read C again for.
+ *              Sum the rows in order (gm3d_colsum_finish) -> the input of gm3d_bn_finalize.  Deterministic. */
+int gm3d_gemm_tn_bf16_ws_bn_apply(const void *A, const void *W, const void *T, const float *scale, const float *shift, float slope, void *C,
+                                  int M, int N, int K, int lda, int ldw, int ldt, int ldc, gm3d_stream_t stream);
+int gm3d_gemm_tn_bf16_ws_bn_stats(const void *A, const void *W, const void *T, void *C, float *partial, int M, int N, int K, int lda,
+                                  int ldw, int ldt, int ldc, gm3d_stream_t stream);
+int gm3d_gemm_ws_stats_rows(int M, int N, int K);
 /* measurement knob: persistent workgroups per CU (1 or 2; two only where the LDS ring allows). Results do not depend on it. */
 int gm3d_gemm_ws_set_occupancy(int wg_per_cu);
 /* The ring kernel with 96-column tiles (N % 96 == 0): N = 384 -- attn.proj, mlp.fc2 and the input gradients of fc1 / qkv / proj of

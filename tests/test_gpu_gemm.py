@@ -364,3 +364,37 @@ def test_gemm_weight_stationary_pool_epilogue(groups, K, N, after, rows):
     warg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
     check(lib.gm3d_group_max_fwd(_ptr(z), _ptr(b) if after else None, _ptr(want), _ptr(warg), groups, 32, N, 1, _stream()), "gmax")
     assert torch.equal(pooled, want) and torch.equal(arg, warg)
+
+
+@pytest.mark.parametrize("groups", [2048, 8192, 1031])
+def test_gemm_weight_stationary_batchnorm_epilogues(groups):
+    """second_conv.0 (256 -> 512) with the BatchNorm behind it inside the product's launch (csrc/gemm_ws.hip EPI 4 / 5):
+    eval mode  -- act((bf16(x W^T) + t[group]) * scale + shift) == the product followed by gm3d_bn_bcast_apply_relu, bit for bit
+                  (negative zeros of slope * h included);
+    train mode -- the product itself unchanged, and the per-workgroup partial sums add up to the statistics gm3d_bn_bcast_stats reads
+                  the product again for (against an fp64 sum of the same bf16 values; two launches give identical bits)."""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    M, K, N = groups * 32, 256, 512
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    t = torch.randn(groups, N, device="cuda", generator=g).bfloat16()
+    scale = torch.randn(N, device="cuda", generator=g)
+    shift = torch.randn(N, device="cuda", generator=g) * 0.3
+    assert gemm.ws_bn_supported(x, w, t)
+    y0 = gemm.linear_tn(x, w)
+    want = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    check(lib.gm3d_bn_bcast_apply_relu(_ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(want), groups, 32, N, 0.0, 1, _stream()), "apply")
+    got = gemm.linear_ws_bn_apply(x, w, t, scale, shift)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    prod, part = gemm.linear_ws_bn_stats(x, w, t)
+    assert torch.equal(prod, y0)
+    prod2, part2 = gemm.linear_ws_bn_stats(x, w, t)
+    assert torch.equal(part, part2)
+    y = (y0.double().view(groups, 32, N) + t.double()[:, None, :]).view(M, N)
+    s1, s2 = y.sum(0), (y * y).sum(0)
+    st = part.double().sum(0)
+    assert float((st[:N] - s1).abs().max()) <= 2e-6 * float(y.abs().sum(0).max())
+    assert float((st[N:] - s2).abs().max()) <= 2e-6 * float(s2.max())
