@@ -152,13 +152,21 @@ __global__ __launch_bounds__(256) void patch_loss_bwd_kernel(const T* __restrict
                                                              const float* __restrict__ target, const long long* __restrict__ ids,
                                                              size_t ids_bstride, const int32_t* __restrict__ i1,
                                                              const int32_t* __restrict__ i2, const float* __restrict__ gmean, int B,
-                                                             int Tn, int M, T* __restrict__ dpred) {
+                                                             int Tn, int M, T* __restrict__ dpred, int lead) {
+    // lead > 0: dpred is the gradient of the FULL (B, lead + M, 96) prediction whose last M patches entered the loss -- the first
+    // `lead` patches of every cloud get zeros (the backward of the [:, -M:] slice in the same launch)
     const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (p >= B * M) return;
-    const int b = p / M, m = p - b * M;
+    const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int LM = lead + M;
+    if (q >= B * LM) return;
+    const int b = q / LM, m = q - b * LM - lead;
     const bool first = lane < 32;
     const int l = lane & 31;
+    if (m < 0) {
+        if (first) { T* out = dpred + (size_t)q * 96 + l * 3; out[0] = (T)0.f; out[1] = (T)0.f; out[2] = (T)0.f; }
+        return;
+    }
+    const int p = b * M + m;
     float mx, my, mz;
     if (first) {
         const T* pp = pred + (size_t)b * pred_bstride + (size_t)m * 96 + l * 3;
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void patch_loss_bwd_kernel(const T* __restrict
         if (sj == l) { ax = __fsub_rn(ax, sx); ay = __fsub_rn(ay, sy); az = __fsub_rn(az, sz); }
     }
     if (first) {
-        T* out = dpred + (size_t)p * 96 + l * 3;
+        T* out = dpred + (size_t)q * 96 + l * 3;
         out[0] = (T)ax; out[1] = (T)ay; out[2] = (T)az;
     }
 }
@@ -326,20 +334,26 @@ extern "C" int gm3d_patch_chamfer_loss_fwd(const void* pred, long long pred_bstr
     return GM3D_OK;
 }
 
-extern "C" int gm3d_patch_chamfer_loss_bwd(const void* pred, long long pred_bstride, const float* target, const long long* ids,
-                                           long long ids_bstride, const int32_t* idx1, const int32_t* idx2, const float* gmean, int B,
-                                           int T, int M, void* dpred, int dtype, gm3d_stream_t stream) {
+extern "C" int gm3d_patch_chamfer_loss_bwd_full(const void* pred, long long pred_bstride, const float* target, const long long* ids,
+                                                long long ids_bstride, const int32_t* idx1, const int32_t* idx2, const float* gmean, int B,
+                                                int T, int M, int lead, void* dpred, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!pred || !target || !ids || !idx1 || !idx2 || !gmean || !dpred || B < 1 || T < 1 || M < 1 || M > T) return GM3D_EINVAL;
+    if (!pred || !target || !ids || !idx1 || !idx2 || !gmean || !dpred || B < 1 || T < 1 || M < 1 || M > T || lead < 0) return GM3D_EINVAL;
     if (pred_bstride < (long long)M * 96 || ids_bstride < M) return GM3D_EINVAL;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    const int P = B * M;
+    const int P = B * (lead + M);
     GM3D_CH_DISPATCH(dtype,
                   hipLaunchKernelGGL(patch_loss_bwd_kernel<bf16_t>, dim3((P + 3) / 4), dim3(256), 0, st, (const bf16_t*)pred,
-                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (bf16_t*)dpred),
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (bf16_t*)dpred, lead),
                   hipLaunchKernelGGL(patch_loss_bwd_kernel<float>, dim3((P + 3) / 4), dim3(256), 0, st, (const float*)pred,
-                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (float*)dpred));
+                                     (size_t)pred_bstride, target, ids, (size_t)ids_bstride, idx1, idx2, gmean, B, T, M, (float*)dpred, lead));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
+}
+
+extern "C" int gm3d_patch_chamfer_loss_bwd(const void* pred, long long pred_bstride, const float* target, const long long* ids,
+                                           long long ids_bstride, const int32_t* idx1, const int32_t* idx2, const float* gmean, int B,
+                                           int T, int M, void* dpred, int dtype, gm3d_stream_t stream) {
+    return gm3d_patch_chamfer_loss_bwd_full(pred, pred_bstride, target, ids, ids_bstride, idx1, idx2, gmean, B, T, M, 0, dpred, dtype, stream);
 }

@@ -493,10 +493,10 @@ __global__ __launch_bounds__(256) void lin3_gelu_bwd_kernel(const T* __restrict_
 // models_mae_learn_loss.py:795-805: pos[i,j] = t_j > t_i, neg[i,j] = t_j < t_i, D = p_j - p_i,
 //   loss = sum(-pos*log(sig(D)+1e-6) - neg*log(1-sig(D)+1e-6)) / sum(pos|neg).   One wave per sample, M <= 64.
 // out[b][0] = sum of the pair terms, out[b][1] = number of ordered pairs; dp[b][k] = d(sum)/dp_k (unnormalised).
-__global__ __launch_bounds__(64) void rank_loss_kernel(const float* __restrict__ p, const float* __restrict__ t, int M,
+__global__ __launch_bounds__(64) void rank_loss_kernel(const float* __restrict__ p, int ldp, const float* __restrict__ t, int M,
                                                        float* __restrict__ out, float* __restrict__ dp) {
     const int b = blockIdx.x, j = threadIdx.x;
-    const float pj = j < M ? p[(size_t)b * M + j] : 0.f, tj = j < M ? t[(size_t)b * M + j] : 0.f;
+    const float pj = j < M ? p[(size_t)b * ldp + j] : 0.f, tj = j < M ? t[(size_t)b * M + j] : 0.f;
     float ls = 0.f, cnt = 0.f, g = 0.f;
     for (int i = 0; i < M; ++i) {
         const float pi = __shfl(pj, i), ti = __shfl(tj, i);
@@ -516,6 +516,58 @@ __global__ __launch_bounds__(64) void rank_loss_kernel(const float* __restrict__
     for (int o = 32; o > 0; o >>= 1) { ls += __shfl_xor(ls, o); cnt += __shfl_xor(cnt, o); }
     if (j == 0) { out[(size_t)b * 2] = ls; out[(size_t)b * 2 + 1] = cnt; }
     if (j < M) dp[(size_t)b * M + j] = g;
+}
+
+// tot[0] = sum_b out[b][0], tot[1] = sum_b out[b][1] (one workgroup, fixed order: per-thread strided partial sums, then a tree), and
+// loss[0] = tot[0] / tot[1]: the .sum(dim=0) and the division of forward_learning_loss in one launch.
+__global__ __launch_bounds__(256) void rank_loss_finish_kernel(const float* __restrict__ out, int B, float* __restrict__ tot,
+                                                               float* __restrict__ loss) {
+    __shared__ float red[2][256];
+    float a = 0.f, c = 0.f;
+    for (int b = threadIdx.x; b < B; b += 256) { a += out[(size_t)b * 2]; c += out[(size_t)b * 2 + 1]; }
+    red[0][threadIdx.x] = a; red[1][threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tot[0] = red[0][0]; tot[1] = red[1][0]; loss[0] = red[0][0] / red[1][0]; }
+}
+
+// d loss / d loss_pred over the FULL (B,L) prediction whose last M columns entered the loss: dfull[b][L - M + j] = dp[b][j] * (g / tot[1]),
+// zeros in front (the slice's backward, the division and the product of the autograd graph in one launch).
+__global__ __launch_bounds__(256) void rank_loss_bwd_kernel(const float* __restrict__ dp, const float* __restrict__ g,
+                                                            const float* __restrict__ tot, int B, int M, int L, float* __restrict__ dfull) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * L) return;
+    const int b = i / L, l = i - b * L, j = l - (L - M);
+    const float s = g[0] / tot[1];
+    dfull[i] = j >= 0 ? dp[(size_t)b * M + j] * s : 0.f;
+}
+
+// DropPath factors floor(keep_s + u) / keep_s for S sites x B samples from one uniform draw u (S,B): the add_, floor_ and div_ of
+// models_mae_learn_loss.drop_path_scales in one launch, the same IEEE operations.
+__global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __restrict__ u, const float* __restrict__ keep, int S, int B,
+                                                               float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= S * B) return;
+    const float k = keep[i / B];
+    out[i] = __fdiv_rn(floorf(__fadd_rn(u[i], k)), k);
+}
+
+// dst (R,Np) = [src (R,N) | zeros]: a narrow matrix padded to a full tile width in one launch (instead of zeros + copy_).  8-element chunks.
+template <class T>
+__global__ __launch_bounds__(256) void pad_cols_kernel(const T* __restrict__ src, size_t lds, int R, int N, T* __restrict__ dst, int Np) {
+    const int cpr = Np >> 3;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)R * cpr) return;
+    const size_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    if (c < N) V8<T>::load(src + r * lds + c, v);
+    V8<T>::store(dst + r * (size_t)Np + c, v);
 }
 
 // ------------------------------------------------------------------ BatchNorm statistic finalisation (one tiny launch)
@@ -627,7 +679,7 @@ __global__ void pn1_bwd_finalize_kernel(const double* __restrict__ q, const doub
 __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict__ loss_pred, const float* __restrict__ noise,
                                                          int L, int len_keep, int len_loss, float* __restrict__ mask,
                                                          long long* __restrict__ vis_ids, long long* __restrict__ mask_ids,
-                                                         int vis_pitch, int mask_pitch) {
+                                                         int vis_pitch, int mask_pitch, unsigned char* __restrict__ mask_b = nullptr) {
     const int b = blockIdx.x, l = threadIdx.x;
     const bool in = l < L;
     const float lp = in ? loss_pred[(size_t)b * L + l] : 0.f;
@@ -648,6 +700,7 @@ __global__ __launch_bounds__(64) void mask_select_kernel(const float* __restrict
     const unsigned long long below = l == 0 ? 0ull : (~0ull >> (64 - l));
     if (in) {
         mask[(size_t)b * L + l] = keep ? 0.f : 1.f;
+        if (mask_b) mask_b[(size_t)b * L + l] = keep ? 0 : 1;
         if (keep) vis_ids[(size_t)b * vis_pitch + __popcll(kb & below)] = l;
         else mask_ids[(size_t)b * mask_pitch + __popcll(mb & below)] = l;
     }
@@ -1209,7 +1262,52 @@ extern "C" int gm3d_rank_loss(const float* pred, const float* target, int B, int
     using namespace gm3d;
     if (!pred || !target || !out || !dpred || B < 1 || M < 1) return GM3D_EINVAL;
     if (M > 64) return GM3D_EUNSUPPORTED;
-    hipLaunchKernelGGL(rank_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, target, M, out, dpred);
+    hipLaunchKernelGGL(rank_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, M, target, M, out, dpred);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_rank_loss_tail(const float* pred, int ldp, const float* target, int B, int M, float* out, float* dpred, float* tot,
+                                   float* loss, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!pred || !target || !out || !dpred || !tot || !loss || B < 1 || M < 1 || ldp < M) return GM3D_EINVAL;
+    if (M > 64) return GM3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(rank_loss_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, pred, ldp, target, M, out, dpred);
+    GM3D_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rank_loss_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)out, B, tot, loss);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_rank_loss_tail_bwd(const float* dpred, const float* g, const float* tot, int B, int M, int L, float* dfull,
+                                       gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dpred || !g || !tot || !dfull || B < 1 || M < 1 || L < M) return GM3D_EINVAL;
+    hipLaunchKernelGGL(rank_loss_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpred, g, tot, B, M, L, dfull);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_drop_path_scales(const float* u, const float* keep, int S, int B, float* out, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!u || !keep || !out || S < 1 || B < 1) return GM3D_EINVAL;
+    hipLaunchKernelGGL(drop_path_scales_kernel, dim3((S * B + 255) / 256), dim3(256), 0, (hipStream_t)stream, u, keep, S, B, out);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_pad_cols(const void* src, long long lds, int R, int N, void* dst, int Np, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!src || !dst || R < 1 || N < 1 || Np < N || lds < N) return GM3D_EINVAL;
+    if (N % 8 || Np % 8 || lds % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    const size_t n = (size_t)R * (Np / 8);
+    hipStream_t st = (hipStream_t)stream;
+    GM3D_DISPATCH(dtype,
+                  hipLaunchKernelGGL(pad_cols_kernel<bf16_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)src, (size_t)lds, R,
+                                     N, (bf16_t*)dst, Np),
+                  hipLaunchKernelGGL(pad_cols_kernel<float>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)src, (size_t)lds, R, N,
+                                     (float*)dst, Np));
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -1249,8 +1347,16 @@ extern "C" int gm3d_pn1_bwd_finalize(const double* q, const double* mcov, const 
     return GM3D_OK;
 }
 
+extern "C" int gm3d_mask_select_b(const float* loss_pred, const float* noise, int B, int L, int len_keep, int len_loss, float* mask,
+                                  unsigned char* mask_bool, long long* vis_ids, long long* mask_ids, int id_pitch, gm3d_stream_t stream);
+
 extern "C" int gm3d_mask_select(const float* loss_pred, const float* noise, int B, int L, int len_keep, int len_loss,
                                 float* mask, long long* vis_ids, long long* mask_ids, int id_pitch, gm3d_stream_t stream) {
+    return gm3d_mask_select_b(loss_pred, noise, B, L, len_keep, len_loss, mask, nullptr, vis_ids, mask_ids, id_pitch, stream);
+}
+
+extern "C" int gm3d_mask_select_b(const float* loss_pred, const float* noise, int B, int L, int len_keep, int len_loss, float* mask,
+                                  unsigned char* mask_bool, long long* vis_ids, long long* mask_ids, int id_pitch, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!loss_pred || !noise || !mask || !vis_ids || !mask_ids || B < 0 || L < 1) return GM3D_EINVAL;
     if (len_keep < 0 || len_loss < 0 || len_keep + len_loss > L) return GM3D_EINVAL;
@@ -1258,7 +1364,7 @@ extern "C" int gm3d_mask_select(const float* loss_pred, const float* noise, int 
     if (B == 0) return GM3D_OK;
     if (id_pitch != 0 && id_pitch < L) return GM3D_EINVAL;
     hipLaunchKernelGGL(mask_select_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, loss_pred, noise, L, len_keep, len_loss,
-                       mask, vis_ids, mask_ids, id_pitch ? id_pitch : len_keep, id_pitch ? id_pitch : L - len_keep);
+                       mask, vis_ids, mask_ids, id_pitch ? id_pitch : len_keep, id_pitch ? id_pitch : L - len_keep, mask_bool);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -158,13 +158,26 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 
     for (int i = 0; i < nmine; ++i) {
         const int m0 = (first + i * stride) * (32 * TM);
-        wbf16x4 tq[TM][4];
-        if (EPI == 4 || EPI == 5) {                  // the groups' row of T: in flight while the tile is multiplied
+        // EPI 4 / 5: the groups' row of T by SCALAR loads (uniform address, constant address space: lgkmcnt, not vmcnt -- a vector load
+        // here would make the wave wait for the previous tile's global stores as well); 32 columns of this wave = 16 dwords
+        float tq[TM][4][4];
+        if (EPI == 4 || EPI == 5) {
+            typedef const __attribute__((address_space(4))) unsigned int* sptr_t;
 #pragma unroll
-            for (int t = 0; t < TM; ++t)
+            for (int t = 0; t < TM; ++t) {
+                sptr_t tp = (sptr_t)(const void*)(bn.T + (size_t)((m0 >> 5) + t) * bn.ldt + n0 + 32 * w);
+                unsigned tw[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) tw[j] = tp[j];
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    tq[t][q] = *reinterpret_cast<const wbf16x4*>(bn.T + (size_t)((m0 >> 5) + t) * bn.ldt + n0 + 32 * w + 8 * q + 4 * hh);
+#pragma unroll
+                    for (int e2 = 0; e2 < 2; ++e2) {
+                        const unsigned u = hh ? tw[4 * q + 2 + e2] : tw[4 * q + e2];      // columns 8 q + 4 hh + 2 e2 (+1)
+                        tq[t][q][2 * e2] = __builtin_bit_cast(float, u << 16);
+                        tq[t][q][2 * e2 + 1] = __builtin_bit_cast(float, u & 0xffff0000u);
+                    }
+            }
         }
         __builtin_amdgcn_s_barrier();                // B1
         const unsigned char* as = wsm + (i % NT) * TILE;
@@ -255,11 +268,11 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                     for (int e = 0; e < 4; ++e) {
                         pk[e] = (bf16_t)(acc[t][4 * q + e] + bq[q][e]);
                         if (EPI == 4) {
-                            const float h = ((float)pk[e] + (float)tq[t][q][e]) * bn_a[q][e] + bn_b[q][e];
+                            const float h = ((float)pk[e] + tq[t][q][e]) * bn_a[q][e] + bn_b[q][e];
                             pk[e] = (bf16_t)(h > 0.f ? h : bn.slope * h);
                         }
                         if (EPI == 5) {
-                            const float y = (float)pk[e] + (float)tq[t][q][e];
+                            const float y = (float)pk[e] + tq[t][q][e];
                             bn_a[q][e] += y;
                             bn_b[q][e] += y * y;
                         }

@@ -405,8 +405,23 @@ def _arange_ids(B, L, device):
     return _arange_cache[key]
 
 
+_const_cache = {}
+
+
+def _const_scalar(device, value):
+    """a cached f32 0-d constant on `device` (created outside stream capture only: see models_mae_learn_loss._zero_scalar)."""
+    key = (str(device), float(value))
+    c = _const_cache.get(key)
+    if c is None:
+        c = torch.full((), float(value), dtype=torch.float32, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _const_cache[key] = c
+    return c
+
+
 def backward_and_collect(total, raw, optimizer, grad_sync, accum=1, accum_first=True, accum_last=True, async_w=True):
     """zero (first micro-batch of the window) -> backward -> gradients where the update / all-reduce expects them.
+    total: the scalar objective (already divided by accum), or a tuple of scalar losses whose sum / accum is the objective.
     Shared by this engine and engine_pretrain_Classifier_SVM."""
     flat_opt = optimizer is not None and hasattr(optimizer, "flat_grad_views")
     flat_sync = grad_sync is not None and getattr(grad_sync, "_flat", None) is not None and flat_opt
@@ -424,8 +439,14 @@ def backward_and_collect(total, raw, optimizer, grad_sync, accum=1, accum_first=
                 p.grad = None
     from .fused import async_wgrad
     # the encoder stack's weight-gradient GEMMs beside the embed's backward; joined on exit
-    with (async_wgrad(total.device) if async_w else nullcontext()):
-        total.backward()
+    roots = list(total) if isinstance(total, (tuple, list)) else None
+    dev = roots[0].device if roots else total.device
+    with (async_wgrad(dev) if async_w else nullcontext()):
+        if roots:     # several scalar losses whose sum / accum is the objective: seeded with a cached constant 1 / accum each
+            seed = _const_scalar(dev, 1.0 / accum)
+            torch.autograd.backward(roots, [seed] * len(roots))
+        else:
+            total.backward()
     if flat_opt and (flat_sync or accum > 1):
         optimizer.gather_grads()   # one multi-tensor copy into the flat buffer the all-reduce works on
         if accum > 1:
@@ -460,26 +481,30 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
             all_ids = (_arange_ids(B, L, samples.device), _arange_ids(B, 0, samples.device))
             outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False, ids=all_ids)
             ids = None
-            if samples.is_cuda and L <= 64:       # mask + visible / masked id lists in one launch
-                mask, vis_ids, mask_ids = teacher.generate_mask_ids(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True,
-                                                                    epoch=epoch, total_epoch=args.epochs, noise=mask_noise)
+            if samples.is_cuda and L <= 64:       # mask (f32 and bool) + visible / masked id lists in one launch
+                mask, vis_ids, mask_ids, bool_masked_pos = teacher.generate_mask_ids(
+                    outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch, total_epoch=args.epochs, noise=mask_noise,
+                    want_bool=True)
                 ids = (vis_ids, mask_ids)
             else:
                 mask = teacher.generate_mask(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch,
                                              total_epoch=args.epochs, noise=mask_noise)
-            bool_masked_pos = mask.flatten(1).to(torch.bool)
+                bool_masked_pos = mask.flatten(1).to(torch.bool)
         outs = model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, ids=ids)
         M = outs["mask_num"]
+        # the two losses read the last M tokens of the full predictions: passed whole (full_pred=) so that the fused losses fold the
+        # slice and its zero-filling backward in
         loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"],
-                                     mask_ids=ids[1] if ids is not None else None)
+                                     mask_ids=ids[1] if ids is not None else None, full_pred=outs["pix_pred"])
         loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
         # P/:153: 13.889 * MSE + 1.0 * Chamfer; MSE is identically 0 in this variant (no launches, forward or backward, for it)
         loss = loss_chfr if loss_outs.get("MSE_zero") else 13.889 * loss_mse + 1.0 * loss_chfr
         loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos,
-                                               loss_outs["matrix"].detach(), relative=args.relative)
+                                               loss_outs["matrix"].detach(), relative=args.relative, full_pred=outs["loss_pred"])
     accum = getattr(args, "accum_iter", 1)
-    total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum         # P/:190,195
-    backward_and_collect(total, raw, optimizer, grad_sync, accum, accum_first, accum_last)
+    # P/:190,195: (loss + loss_learn) / accum_iter -> backward.  Two roots seeded with the constant 1 / accum_iter: the same gradients
+    # without the sum, the division and the ones_like launch
+    backward_and_collect((loss, loss_learn), raw, optimizer, grad_sync, accum, accum_first, accum_last)
     return {"loss": loss.detach(), "loss_learn": loss_learn.detach(), "loss_chfr": loss_chfr.detach(),
             "loss_mse": loss_mse.detach(), "mask": bool_masked_pos, "matrix": loss_outs["matrix"].detach(),
             "teacher_loss_pred": outs_ema["loss_pred"]}
@@ -728,9 +753,9 @@ class SegmentedDDPStep:
                 group = teacher.group_divider(samples)
                 all_ids = (_arange_ids(B, L, samples.device), _arange_ids(B, 0, samples.device))
                 outs_ema = teacher(samples, mask=visible_mask, num_visible=L, group=group, need_pix_pred=False, ids=all_ids)
-                mask, vis_ids, mask_ids = teacher.generate_mask_ids(outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True,
-                                                                    epoch=epoch, total_epoch=args.epochs, noise=self.static_noise)
-                bool_masked_pos = mask.flatten(1).to(torch.bool)
+                mask, vis_ids, mask_ids, bool_masked_pos = teacher.generate_mask_ids(
+                    outs_ema["loss_pred"], mask_ratio=args.mask_ratio, guide=True, epoch=epoch, total_epoch=args.epochs, noise=self.static_noise,
+                    want_bool=True)
             from . import models_mae_learn_loss as MM
             vis_only = MM.VISIBLE_EMBED and raw.encoder.fused(group[0]) and vis_ids.shape[1] < L
             # segment 2 | segment 1 boundary: the encoder sees detached leaves (the visible tokens only, when the embed can stop there)
@@ -740,16 +765,17 @@ class SegmentedDDPStep:
             outs = self.model(samples, mask=bool_masked_pos, num_visible=len_keep, group=group, tokens=tokens_d, pos_all=pos_all_d,
                               ids=(vis_ids, mask_ids), cut=True, tokens_visible=vis_only)
             M = outs["mask_num"]
-            loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"], mask_ids=mask_ids)
+            loss_outs = raw.forward_loss(outs["pix_pred"][:, -M:], outs["neighborhood"], outs["mask"], mask_ids=mask_ids,
+                                         full_pred=outs["pix_pred"])
             loss_mse, loss_chfr = loss_outs["MSE_mean"], loss_outs["Chamfer_mean"]
             loss = loss_chfr if loss_outs.get("MSE_zero") else 13.889 * loss_mse + 1.0 * loss_chfr
             loss_learn = raw.forward_learning_loss(outs["loss_pred"][:, -M:], bool_masked_pos, loss_outs["matrix"].detach(),
-                                                   relative=args.relative)
+                                                   relative=args.relative, full_pred=outs["loss_pred"])
         accum = getattr(args, "accum_iter", 1)
-        total = loss + loss_learn if accum == 1 else (loss + loss_learn) / accum
         x_vis_d, pos_full_d = outs["features"], outs["pos_full"]   # segment 1 | segment 0 boundary (detached leaves)
         p0 = self.seg_params[0]
-        g = torch.autograd.grad(total, p0 + [x_vis_d, pos_full_d], allow_unused=True)
+        seed = _const_scalar(loss.device, 1.0 / accum)             # two roots seeded with 1 / accum: no sum, division, ones_like
+        g = torch.autograd.grad([loss, loss_learn], p0 + [x_vis_d, pos_full_d], grad_outputs=[seed, seed], allow_unused=True)
         self._store(0, g[:len(p0)])
         self._cut1 = outs["cut"] + (g[len(p0)], g[len(p0) + 1])
         self._cut2 = (tokens, pos_all, tokens_d, pos_all_d)

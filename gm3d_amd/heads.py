@@ -72,8 +72,8 @@ class LinearBiasFn(torch.autograd.Function):
             if (adt == torch.bfloat16 and N < 128 and K % 128 == 0
                     and gemm.wgrad_supported(dy2.new_empty(1, R, 128), x2.unsqueeze(0))):
                 # narrow layer (N = 96): dy and W^T zero-padded to one 128-wide tile, shared by both products
-                pad = torch.zeros(R, 128, dtype=adt, device=dy2.device)
-                pad[:, :N] = dy2
+                pad = torch.empty(R, 128, dtype=adt, device=dy2.device)
+                _launch("gm3d_pad_cols", {"R": R, "N": N}, lib.gm3d_pad_cols, _ptr(dy2), dy2.stride(0), R, N, _ptr(pad), 128, _DT[adt], _stream())
                 wt = torch.zeros(K, 128, dtype=adt, device=dy2.device)
                 wt[:, :N] = W.t()
                 dx = gemm.mm(pad, wt).view(ctx.shp).to(ctx.xdt)
@@ -530,6 +530,44 @@ class _RankLoss(torch.autograd.Function):
         return (dp * (g / tot[1])).to(ctx.pdt), None
 
 
+class _RankLossTail(torch.autograd.Function):
+    """loss_learn on the last M columns of the full (B,L) f32 prediction: kernel + fixed-order finish (2 launches), backward ONE launch
+    that writes the gradient of the full prediction (zeros in front) -- no slice, clone, sum, division or product on the PyTorch side."""
+
+    @staticmethod
+    def forward(ctx, pred_full, M, target):
+        with torch.autocast("cuda", enabled=False):
+            B, L = pred_full.shape
+            dev = pred_full.device
+            t = target.detach().float().contiguous()
+            out = torch.empty(B, 2, dtype=torch.float32, device=dev)
+            dp = torch.empty(B, M, dtype=torch.float32, device=dev)
+            tot = torch.empty(2, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            _launch("gm3d_rank_loss_tail", {"B": B, "M": M}, lib.gm3d_rank_loss_tail, pred_full.data_ptr() + 4 * (L - M), pred_full.stride(0),
+                    _ptr(t), B, M, _ptr(out), _ptr(dp), _ptr(tot), _ptr(loss), _stream())
+            ctx.save_for_backward(dp, tot)
+            ctx.dims = (B, M, L)
+            return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        dp, tot = ctx.saved_tensors
+        B, M, L = ctx.dims
+        g = g.detach().reshape(1).float().contiguous()
+        dfull = torch.empty(B, L, dtype=torch.float32, device=dp.device)
+        _launch("gm3d_rank_loss_tail_bwd", {"B": B, "M": M, "L": L}, lib.gm3d_rank_loss_tail_bwd, _ptr(dp), _ptr(g), _ptr(tot), B, M, L,
+                _ptr(dfull), _stream())
+        return dfull, None, None
+
+
+def rank_loss_tail(pred_full, M, target):
+    """rank_loss(pred_full[:, -M:], target) with the slice folded in; pred_full (B,L) f32, unit inner stride."""
+    if pred_full.dtype == torch.float32 and pred_full.dim() == 2 and pred_full.stride(1) == 1 and 1 <= M <= min(64, pred_full.shape[1]):
+        return _RankLossTail.apply(pred_full, M, target)
+    return _RankLoss.apply(pred_full[:, -M:], target)
+
+
 class PatchChamferLossFn(torch.autograd.Function):
     """forward_loss of the north-star model on the masked patches in one pass (csrc/chamfer.hip patch_loss_*): pred (B,M,96) -- a
     batch-strided view of the decoder head's (B,L,96) output is taken as it is --, target (B,T,32,3) f32, mask_ids (B,M) int64
@@ -537,7 +575,14 @@ class PatchChamferLossFn(torch.autograd.Function):
     ranking target, P/engine_pretrain.py:156-171)."""
 
     @staticmethod
-    def forward(ctx, pred, target, mask_ids):
+    def forward(ctx, pred, target, mask_ids, full=False):
+        # full=True: pred is the whole (B,L,96) prediction, contiguous; its last M patches enter the loss and the backward returns the
+        # gradient of the whole tensor (zeros for the visible patches) -- the [:, -M:] slice and its zero-filling backward folded in
+        ctx.set_materialize_grads(False)
+        ctx.lead = 0
+        if full:
+            ctx.lead = pred.shape[1] - mask_ids.shape[1]
+            pred = pred.detach()[:, ctx.lead:]
         B, M, _ = pred.shape
         T = target.shape[1]
         dev = pred.device
@@ -556,12 +601,14 @@ class PatchChamferLossFn(torch.autograd.Function):
     def backward(ctx, g, _gm):
         pred, target, mask_ids, i1, i2 = ctx.saved_tensors
         B, M, _ = pred.shape
+        if g is None:
+            return None, None, None, None
         g = g.detach().reshape(1).float().contiguous()
-        dpred = torch.empty(B, M, 96, dtype=pred.dtype, device=pred.device)
-        _launch("gm3d_patch_chamfer_loss_bwd", {"B": B, "M": M, "dtype": str(pred.dtype)}, lib.gm3d_patch_chamfer_loss_bwd, _ptr(pred),
+        dpred = torch.empty(B, ctx.lead + M, 96, dtype=pred.dtype, device=pred.device)
+        _launch("gm3d_patch_chamfer_loss_bwd", {"B": B, "M": M, "dtype": str(pred.dtype)}, lib.gm3d_patch_chamfer_loss_bwd_full, _ptr(pred),
                 pred.stride(0), _ptr(target), _ptr(mask_ids), mask_ids.stride(0), _ptr(i1), _ptr(i2), _ptr(g), B, target.shape[1], M,
-                _ptr(dpred), _DT[pred.dtype], _stream())
-        return dpred, None, None
+                ctx.lead, _ptr(dpred), _DT[pred.dtype], _stream())
+        return dpred, None, None, None
 
 
 FUSED_PATCH_LOSS = True

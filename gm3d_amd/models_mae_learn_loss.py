@@ -47,6 +47,19 @@ def drop_path_scale(B, p, training, device):
 
 
 _default_drop_path_scale = drop_path_scale
+_zero_cache = {}
+
+
+def _zero_scalar(device):
+    """a constant f32 0-d zero on `device`, created once OUTSIDE any stream capture (a tensor first filled inside a capture holds
+    nothing until the first replay); while capturing without one, a fresh zeros(()) as before."""
+    key = str(device)
+    z = _zero_cache.get(key)
+    if z is None:
+        z = torch.zeros((), dtype=torch.float32, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _zero_cache[key] = z
+    return z
 
 
 _keep_cache = {}
@@ -64,7 +77,14 @@ def _draw_scales(B, plist, device):
         if keep is None:   # built once (outside any stream capture: the eager warm-up steps come first)
             keep = torch.tensor([1.0 - p for p in key[0]], dtype=torch.float32).unsqueeze(1).to(device)
             _keep_cache[key] = keep
-        s = (torch.rand(len(flat), B, dtype=torch.float32, device=device) + keep).floor_().div_(keep)
+        u = torch.rand(len(flat), B, dtype=torch.float32, device=device)
+        if u.is_cuda:         # floor(keep + u) / keep: the same three IEEE operations in one launch
+            from ._capi import lib
+            s = torch.empty_like(u)
+            ops._launch("gm3d_drop_path_scales", {"S": len(flat), "B": B}, lib.gm3d_drop_path_scales, ops._ptr(u), ops._ptr(keep), len(flat), B,
+                        ops._ptr(s), ops._stream())
+        else:
+            s = (u + keep).floor_().div_(keep)
         for j, (si, i, _) in enumerate(flat):
             outs[si][i] = s[j]
     return outs
@@ -307,9 +327,9 @@ def take(x, ids):
 
 
 @torch.no_grad()
-def generate_mask_ids(loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None):
+def generate_mask_ids(loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None, want_bool=False):
     """Teacher-guided mask (P/:744-784) plus the id lists split_ids would derive from it, as ONE launch (gm3d_mask_select):
-    -> (mask (B,L) f32 0 keep / 1 remove, vis_ids (B,len_keep) int64, mask_ids (B,L-len_keep) int64).  L <= 64."""
+    -> (mask (B,L) f32 0 keep / 1 remove, vis_ids (B,len_keep) int64, mask_ids (B,L-len_keep) int64[, the mask as bool]).  L <= 64."""
     from ._capi import lib
     N, L = loss_pred.shape
     len_keep = int(L * (1 - mask_ratio))
@@ -323,8 +343,11 @@ def generate_mask_ids(loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epo
     mask = torch.empty(N, L, dtype=torch.float32, device=dev)
     order = torch.empty(N, L, dtype=torch.int64, device=dev)        # [visible ids | masked ids] per sample
     vis_ids, mask_ids = order[:, :len_keep], order[:, len_keep:]
-    ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
-                len_loss, ops._ptr(mask), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
+    mask_b = torch.empty(N, L, dtype=torch.bool, device=dev) if want_bool else None
+    ops._launch("gm3d_mask_select", {"B": N, "L": L}, lib.gm3d_mask_select_b, ops._ptr(lp), ops._ptr(noise), N, L, len_keep,
+                len_loss, ops._ptr(mask), ops._ptr(mask_b), ops._ptr(vis_ids), ops._ptr(mask_ids), L, ops._stream())
+    if want_bool:
+        return mask, vis_ids, mask_ids, mask_b
     return mask, vis_ids, mask_ids
 
 
@@ -504,8 +527,10 @@ class MaskedAutoencoderViT(nn.Module):
             "center": center,
         }
 
-    def forward_loss(self, pred, target, mask, mask_ids=None):
-        """pred (B,M,96) = pix_pred[:, -M:], target = neighborhood (B,64,32,3), mask (B,64) bool (P/:384-412)."""
+    def forward_loss(self, pred, target, mask, mask_ids=None, full_pred=None):
+        """pred (B,M,96) = pix_pred[:, -M:], target = neighborhood (B,64,32,3), mask (B,64) bool (P/:384-412).
+        full_pred: the whole pix_pred (B,L,96) `pred` was sliced from (optional): the fused loss then takes the slice itself and its
+        backward returns the whole tensor's gradient (no separate zero-fill + copy for the slice)."""
         N, t, n, D = target.shape
         M = pred.shape[1]
         if mask_ids is None:
@@ -513,8 +538,12 @@ class MaskedAutoencoderViT(nn.Module):
         if FUSED_HEADS:
             from . import heads
             if heads.patch_chamfer_loss_supported(pred, target, mask_ids):       # gather + cast + Chamfer + both means: one pass
-                mean, matrix = heads.PatchChamferLossFn.apply(pred, target, mask_ids)
-                return {"MSE_mean": mean.detach() * 0.0, "Chamfer_mean": mean, "matrix": matrix, "MSE_zero": True}
+                if full_pred is not None and full_pred.is_contiguous() and full_pred.shape[1] >= M:
+                    mean, matrix = heads.PatchChamferLossFn.apply(full_pred, target, mask_ids, True)
+                else:
+                    mean, matrix = heads.PatchChamferLossFn.apply(pred, target, mask_ids)
+                # "MSE_mean" is identically zero in this variant: a cached constant, no launch (the engines read "MSE_zero")
+                return {"MSE_mean": _zero_scalar(mean.device), "Chamfer_mean": mean, "matrix": matrix, "MSE_zero": True}
         target = take(target, mask_ids).reshape(-1, n, D).to(torch.float32)
         pred = pred.reshape(-1, n, D).to(torch.float32)
         loss = self.loss_func(pred, target).reshape(N, -1, n)
@@ -550,16 +579,19 @@ class MaskedAutoencoderViT(nn.Module):
         return mask
 
     @torch.no_grad()
-    def generate_mask_ids(self, loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None):
+    def generate_mask_ids(self, loss_pred, mask_ratio=0.75, guide=True, epoch=0, total_epoch=200, noise=None, want_bool=False):
         """generate_mask plus the id lists split_ids would derive from it, as ONE launch (module-level generate_mask_ids)."""
-        return generate_mask_ids(loss_pred, mask_ratio, guide, epoch, total_epoch, noise)
+        return generate_mask_ids(loss_pred, mask_ratio, guide, epoch, total_epoch, noise, want_bool)
 
-    def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False):
-        """P/:786-815.  relative=True: pairwise ranking BCE over masked tokens."""
+    def forward_learning_loss(self, loss_pred, mask, loss_target, relative=False, full_pred=None):
+        """P/:786-815.  relative=True: pairwise ranking BCE over masked tokens.  full_pred: the (B,L) prediction loss_pred =
+        full_pred[:, -M:] was sliced from (optional; the fused loss then folds the slice and its backward in)."""
         loss_pred = loss_pred.float()
         loss_target = loss_target.float()
         if relative and FUSED_HEADS and loss_pred.is_cuda and loss_pred.shape[1] <= 64:
             from . import heads
+            if full_pred is not None and full_pred.dtype == torch.float32:
+                return heads.rank_loss_tail(full_pred, loss_pred.shape[1], loss_target)
             return heads.rank_loss(loss_pred, loss_target)
         if relative:
             pos = loss_target.unsqueeze(1) > loss_target.unsqueeze(2)

@@ -129,6 +129,11 @@ int gm3d_patch_chamfer_loss_fwd(const void *pred, long long pred_bstride, const 
 int gm3d_patch_chamfer_loss_bwd(const void *pred, long long pred_bstride, const float *target, const long long *ids,
                                 long long ids_bstride, const int32_t *idx1, const int32_t *idx2, const float *gmean, int B, int T,
                                 int M, void *dpred, int dtype, gm3d_stream_t stream);
+/* ... as the gradient of the FULL prediction (B, lead + M, 96) whose last M patches entered the loss (outs['pix_pred'][:, -M:],
+ * engine_pretrain.py:131): the first `lead` patches of every cloud receive zeros -- the slice's backward in the same launch. */
+int gm3d_patch_chamfer_loss_bwd_full(const void *pred, long long pred_bstride, const float *target, const long long *ids,
+                                     long long ids_bstride, const int32_t *idx1, const int32_t *idx2, const float *gmean, int B, int T,
+                                     int M, int lead, void *dpred, int dtype, gm3d_stream_t stream);
 
 /* Plain LayerNorm over (R, C) rows, 4 <= C <= 512, C % 4 == 0 (nn.LayerNorm of the 96 / 192 / 384-wide Point-M2AE levels):
  * h = (x - mean) * rstd * gamma + beta in `dtype`, mean / rstd (R) f32 saved for the backward.  Backward: dx in `dtype`;
@@ -304,6 +309,16 @@ int gm3d_lin3_gelu_bwd(const void *dout, const float *x, const float *w, const f
  * out (B,2) f32 = [sum of pair terms, number of ordered pairs]; dpred (B,M) = d(sum of pair terms)/d pred.  M <= 64. */
 int gm3d_rank_loss(const float *pred, const float *target, int B, int M, float *out, float *dpred,
                    gm3d_stream_t stream);
+/* The whole loss_learn of engine_pretrain.py:156-171 on the last M columns of a (B, ldp)-pitched prediction (pred points at the first
+ * of them): gm3d_rank_loss plus tot (2) = column sums of out in a fixed order and loss (1) = tot[0] / tot[1] -- two launches, no
+ * PyTorch reduction.  _bwd: dfull (B,L) = [zeros (L - M) | dpred * (g[0] / tot[1])], the gradient of the full (B,L) prediction. */
+int gm3d_rank_loss_tail(const float *pred, int ldp, const float *target, int B, int M, float *out, float *dpred, float *tot, float *loss,
+                        gm3d_stream_t stream);
+int gm3d_rank_loss_tail_bwd(const float *dpred, const float *g, const float *tot, int B, int M, int L, float *dfull, gm3d_stream_t stream);
+/* DropPath factors out (S,B) = floor(keep[s] + u[s][b]) / keep[s] from one uniform draw u (timm DropPath, P/models/Point_MAE.py:9). */
+int gm3d_drop_path_scales(const float *u, const float *keep, int S, int B, float *out, gm3d_stream_t stream);
+/* dst (R,Np) = [src (R,N), row pitch lds | zeros]; N, Np, lds multiples of 8 (a narrow operand padded to a GEMM tile width). */
+int gm3d_pad_cols(const void *src, long long lds, int R, int N, void *dst, int Np, int dtype, gm3d_stream_t stream);
 
 /* ---- Optimizer step on flat buffers (gm3d_amd/csrc/optim.hip) ------------------------------------------------------
  * clip_grad_norm_(max_norm) + torch.optim.AdamW + timm ModelEma.update + bf16 shadows, replacing
@@ -351,6 +366,9 @@ int gm3d_pn1_bwd_finalize(const double *q, const double *mcov, const float *w, c
  * of one (B,id_pitch) buffer gives the [visible | masked] permutation gm3d_token_assemble_* consume). */
 int gm3d_mask_select(const float *loss_pred, const float *noise, int B, int L, int len_keep, int len_loss, float *mask,
                      long long *vis_ids, long long *mask_ids, int id_pitch, gm3d_stream_t stream);
+/* ... with the mask also as bytes (mask_bool (B,L) 0 / 1 or NULL): bool_masked_pos of engine_pretrain.py:100 without a conversion pass. */
+int gm3d_mask_select_b(const float *loss_pred, const float *noise, int B, int L, int len_keep, int len_loss, float *mask,
+                       unsigned char *mask_bool, long long *vis_ids, long long *mask_ids, int id_pitch, gm3d_stream_t stream);
 /* C (M,N) bf16 = A (M,K) bf16 . W (N,K)^T bf16 (+ bias (N) f32), fp32 accumulation: nn.Linear / Conv1d(k=1) forward with W the
  * weight as stored, input gradient with W the transposed weight.  Row pitches lda / ldw / ldc in elements (multiples of 8).
  * Limits: N % 128 == 0, K % 64 == 0. */

@@ -209,3 +209,65 @@ def test_take_rows_deterministic_backward(dtype):
             x.grad = None
             heads.take_rows(x, ids).backward(dy)
             assert torch.equal(x.grad, first)
+
+
+def test_rank_loss_tail_folds_slice_and_reductions():
+    """heads.rank_loss_tail(full, M, target): the ranking loss on full[:, -M:] with the slice, the .sum(0), the division and (backward)
+    the scaling + zero-filled slice gradient inside our launches == heads.rank_loss on the sliced tensor (loss within fp32 summation
+    order of the 128 per-sample terms; gradient identical up to that scale), zeros in front."""
+    from gm3d_amd import heads
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for B, L, M in ((128, 64, 39), (7, 64, 64), (33, 40, 2)):
+        full = torch.randn(B, L, device="cuda", generator=g).requires_grad_(True)
+        target = torch.rand(B, M, device="cuda", generator=g)
+        a = heads.rank_loss_tail(full, M, target)
+        (a * 1.7).backward()
+        ga = full.grad.clone()
+        full.grad = None
+        b = heads.rank_loss(full[:, -M:], target)
+        (b * 1.7).backward()
+        assert abs(float(a) - float(b)) <= 2e-6 * abs(float(b)) + 1e-7
+        assert bool((ga[:, :L - M] == 0).all())
+        assert float((ga - full.grad).abs().max()) <= 2e-6 * float(full.grad.abs().max()) + 1e-12
+
+
+def test_drop_path_scales_kernel_equals_torch_ops():
+    """gm3d_drop_path_scales == (u + keep).floor_().div_(keep) bit for bit (the same three IEEE operations)."""
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    g = torch.Generator(device="cuda").manual_seed(5)
+    u = torch.rand(34, 128, device="cuda", generator=g)
+    keep = (1.0 - torch.linspace(0.003, 0.1, 34, device="cuda")).unsqueeze(1).contiguous()
+    out = torch.empty_like(u)
+    check(lib.gm3d_drop_path_scales(_ptr(u), _ptr(keep), 34, 128, _ptr(out), _stream()), "dp")
+    assert torch.equal(out, (u + keep).floor_().div_(keep))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_pad_cols(dtype):
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream, _DT
+    src = torch.randn(1000, 104, device="cuda").to(dtype)[:, :96]
+    dst = torch.full((1000, 128), 7.0, device="cuda", dtype=dtype)
+    check(lib.gm3d_pad_cols(_ptr(src), src.stride(0), 1000, 96, _ptr(dst), 128, _DT[dtype], _stream()), "pad")
+    assert torch.equal(dst[:, :96], src) and bool((dst[:, 96:] == 0).all())
+
+
+def test_patch_loss_full_prediction_gradient():
+    """PatchChamferLossFn(full=True): the loss of pix_pred[:, -M:] taken from the whole (B,L,96) prediction; backward = the gradient of
+    the whole tensor, zeros for the visible patches, identical to the sliced form + autograd's slice backward."""
+    from gm3d_amd import heads
+    g = torch.Generator(device="cuda").manual_seed(9)
+    B, L, M = 16, 64, 39
+    for dtype in (torch.bfloat16, torch.float32):
+        full = (torch.randn(B, L, 96, device="cuda", generator=g) * 0.3).to(dtype).requires_grad_(True)
+        target = torch.randn(B, L, 32, 3, device="cuda", generator=g) * 0.3
+        ids = torch.stack([torch.randperm(L, device="cuda", generator=g)[:M].sort().values for _ in range(B)])
+        m1, mat1 = heads.PatchChamferLossFn.apply(full, target, ids, True)
+        (m1 * 2.0).backward()
+        g1 = full.grad.clone()
+        full.grad = None
+        m2, mat2 = heads.PatchChamferLossFn.apply(full[:, -M:], target, ids)
+        (m2 * 2.0).backward()
+        assert torch.equal(m1, m2) and torch.equal(mat1, mat2)
+        assert torch.equal(g1, full.grad) and bool((g1[:, :L - M] == 0).all())
