@@ -64,6 +64,7 @@ SIGNATURES = {
     "gm3d_rank_loss": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gm3d_rank_loss_tail": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gm3d_rank_loss_tail_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "gm3d_ema_counters": [_vp, _vp, _i, _f, _f, _vp],
     "gm3d_drop_path_scales": [_vp, _vp, _i, _i, _vp, _vp],
     "gm3d_pad_cols": [_vp, ctypes.c_longlong, _i, _i, _vp, _i, _i, _vp],
     "gm3d_patch_chamfer_loss_bwd_full": [_vp, ctypes.c_longlong, _vp, _vp, ctypes.c_longlong, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp],

@@ -545,6 +545,17 @@ __global__ __launch_bounds__(256) void rank_loss_bwd_kernel(const float* __restr
     dfull[i] = j >= 0 ? dp[(size_t)b * M + j] * s : 0.f;
 }
 
+// ModelEma on the int64 counters (BatchNorm num_batches_tracked): e = (int64)(float(e) * decay + w * float(m)), w = 1 - decay, the arithmetic of
+// e.copy_(e * decay + (1.0 - decay) * m) on int64 tensors (PyTorch computes in fp32 with the Python scalars as float, the converting copy truncates).
+__global__ void ema_counters_kernel(long long* __restrict__ e, const long long* __restrict__ m, int n, float decay, float w) {
+#pragma clang fp contract(off)      // two products and a sum, each rounded (PyTorch runs them as separate kernels): no fma
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float a = (float)e[i] * decay, b = w * (float)m[i];
+        e[i] = (long long)(a + b);
+    }
+}
+
 // DropPath factors floor(keep_s + u) / keep_s for S sites x B samples from one uniform draw u (S,B): the add_, floor_ and div_ of
 // models_mae_learn_loss.drop_path_scales in one launch, the same IEEE operations.
 __global__ __launch_bounds__(256) void drop_path_scales_kernel(const float* __restrict__ u, const float* __restrict__ keep, int S, int B,
@@ -1284,6 +1295,15 @@ extern "C" int gm3d_rank_loss_tail_bwd(const float* dpred, const float* g, const
     using namespace gm3d;
     if (!dpred || !g || !tot || !dfull || B < 1 || M < 1 || L < M) return GM3D_EINVAL;
     hipLaunchKernelGGL(rank_loss_bwd_kernel, dim3((B * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpred, g, tot, B, M, L, dfull);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_ema_counters(long long* e, const long long* m, int n, float decay, float w, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!e || !m || n < 0) return GM3D_EINVAL;
+    if (n == 0) return GM3D_OK;
+    hipLaunchKernelGGL(ema_counters_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, e, m, n, decay, w);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

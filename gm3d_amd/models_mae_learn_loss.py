@@ -478,12 +478,15 @@ class MaskedAutoencoderViT(nn.Module):
             x_vis = x_vis.detach().requires_grad_(True)
             pos_full = pos_full.detach().requires_grad_(True) if pos_full is not None else None
         N = mask_ids.shape[1]
-        if FUSED_HEADS and x_vis.is_cuda:
-            from . import heads
-            mask_tokens = heads.ExpandRowsFn.apply(self.mask_token, B, N, x_vis.dtype)
+        if N == 0 and not torch.is_grad_enabled():
+            x_full = x_vis                      # the teacher's all-visible pass: nothing to append (no cast, no concat launch)
         else:
-            mask_tokens = self.mask_token.expand(B, N, -1).to(x_vis.dtype)
-        x_full = torch.cat([x_vis, mask_tokens], dim=1)
+            if FUSED_HEADS and x_vis.is_cuda:
+                from . import heads
+                mask_tokens = heads.ExpandRowsFn.apply(self.mask_token, B, N, x_vis.dtype)
+            else:
+                mask_tokens = self.mask_token.expand(B, N, -1).to(x_vis.dtype)
+            x_full = torch.cat([x_vis, mask_tokens], dim=1)
         if pos_full is None:
             pos_full = torch.cat([take(pos_all, vis_ids), take(pos_all, mask_ids)], dim=1)
 

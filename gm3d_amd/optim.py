@@ -290,7 +290,13 @@ class FlatAdamWEma(torch.optim.Optimizer):
         self._gathered = False
         g = self.param_groups[0]
         if self.ema is not None:
-            self.ema_w_dev.fill_(1.0 - float(self.ema.decay))
+            # the EMA weight on the device: written only when it changes (once per epoch).  Inside a stream capture the fill is
+            # captured whenever the device may not hold the value yet, and the host-side record is left alone (nothing executes there)
+            w = 1.0 - float(self.ema.decay)
+            if getattr(self, "_ema_w_host", None) != w:
+                self.ema_w_dev.fill_(w)
+                if not (self.ema_w_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
+                    self._ema_w_host = w
         check(lib.gm3d_adamw_ema_flat_step_lrd(
             _ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS), _ptr(self.ES), self.n,
             self.n_decay, _ptr(self.lr_dev), _ptr(self.LS), float(g["weight_decay"]), float(g["betas"][0]),

@@ -315,6 +315,9 @@ int gm3d_rank_loss(const float *pred, const float *target, int B, int M, float *
 int gm3d_rank_loss_tail(const float *pred, int ldp, const float *target, int B, int M, float *out, float *dpred, float *tot, float *loss,
                         gm3d_stream_t stream);
 int gm3d_rank_loss_tail_bwd(const float *dpred, const float *g, const float *tot, int B, int M, int L, float *dfull, gm3d_stream_t stream);
+/* ModelEma.update on the integer buffers (BatchNorm num_batches_tracked, P/engine_pretrain.py:36-52 applies the same blend to every state_dict
+ * entry): e[i] = (int64)(float(e[i]) * decay + w * float(m[i])), w = 1 - decay formed by the caller (in double, like the Python expression). */
+int gm3d_ema_counters(long long *e, const long long *m, int n, float decay, float w, gm3d_stream_t stream);
 /* DropPath factors out (S,B) = floor(keep[s] + u[s][b]) / keep[s] from one uniform draw u (timm DropPath, P/models/Point_MAE.py:9). */
 int gm3d_drop_path_scales(const float *u, const float *keep, int S, int B, float *out, gm3d_stream_t stream);
 /* dst (R,Np) = [src (R,N), row pitch lds | zeros]; N, Np, lds multiples of 8 (a narrow operand padded to a GEMM tile width). */
