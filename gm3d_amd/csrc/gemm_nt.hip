@@ -150,12 +150,172 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
             }
 }
 
+// ---- 128 x 384 output tiles (the block stacks' weight gradients: every (N, K) there is a multiple of (128, 384)) ----------------------
+// The 128 x 128 kernel above reads its fragments and runs its MFMAs in alternating phases (after a stage's barrier every wave is in the
+// same phase) and stages 16 KiB from L2 per 1 MFLOP.  Here: 512 threads, 8 waves x (64 x 96) = 2 x 3 MFMA tiles each -> 32 KiB per
+// 3.1 MFLOP stage (1.5 x the flops per L2 byte), 5 fragments per 6 MFMAs, and a SOFTWARE PIPELINE over the two k-steps of a stage (below).
+// Same stage (32 rows), same order of the sum over rows: results equal to the 128 x 128 kernel's for equal row splits.
+// LDS: per stage four [32][128] images -- dY columns 0..127, X columns 0..383 -- three stages in the ring (96 KiB).  Wave w stages rows
+// 4 w .. 4 w + 3 of every image (4 pieces / stage).
+constexpr int NB_IMG = NT_BR * 256;
+constexpr int NB_STAGE = 4 * NB_IMG;
+constexpr int NB_NBUF = 3;
+
+__global__ __launch_bounds__(512, 1) void gemm_nt384_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
+                                                                 float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
+                                                                 long long sY, long long sX, long long sO, long long sOs, int splits,
+                                                                 int tiles_n, int tiles_k, int total) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    int t = logical;
+    const int tk = t % tiles_k; t /= tiles_k;
+    const int tn = t % tiles_n; t /= tiles_n;
+    const int sp = t % splits;
+    const int b = t / splits;
+    const int n0 = tn * 128, k0 = tk * 384;
+    const bf16_t* Yb = Y + (size_t)b * sY + (size_t)sp * rows_split * ldy + n0;
+    const bf16_t* Xb = X + (size_t)b * sX + (size_t)sp * rows_split * ldx + k0;
+    float* Ob = O + (size_t)b * sO + (size_t)sp * sOs;
+    const int nst = rows_split / NT_BR;
+
+    const int prow = lane >> 4, pcs = lane & 15;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)nsm;
+    const int srow = 4 * w + prow;                              // the row of every image this lane stages
+    const int sch = pcs ^ nt_f(srow);                           // ... and the source chunk that belongs at its LDS slot
+    const size_t yoff = (size_t)srow * ldy + sch * 8, xoff = (size_t)srow * ldx + sch * 8;
+#define GM3D_NB_STAGE(ST)                                                                                    \
+    {                                                                                                        \
+        const unsigned base = lds0 + ((ST) % NB_NBUF) * NB_STAGE + 1024 * w;                                 \
+        const size_t ro = (size_t)(ST) * NT_BR;                                                              \
+        glds16(Yb + ro * ldy + yoff, base);                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 3; ++i) glds16(Xb + ro * ldx + xoff + 128 * i, base + (1 + i) * NB_IMG); \
+    }
+
+    nf32x16 acc[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
+    const int wn = (w >> 2) * 64, wk = (w & 3) * 96;
+    const int cb = 16 * ((lane >> 4) & 1);
+
+    // Software pipeline.  Two fragment sets in registers: while k-step 0's MFMAs run, k-step 1's fragments are read, and while those
+    // run, the NEXT stage's k-step 0 fragments.  Each block is  2 MFMAs | 10 transposed reads of the next set | 4 MFMAs: the first
+    // MFMAs wait for reads issued a block ago (nothing newer is outstanding, so the wait is exact), the reads then issue between MFMAs.
+    // Ring of three stage buffers: passing the barrier of stage st + 1 means every wave has finished READING stage st (each waits for
+    // its own LDS reads first), whose buffer stage st + 3 then refills.
+    // Fragment addresses: 10 per lane (2 + 3 fragments x the two 4-row halves of a transposed read), kept in registers and advanced by
+    // one stage buffer per stage; k-step 1 is the same address + 16 rows (the chunk XOR repeats every 16 rows).
+    unsigned fad[10];
+    {
+        const int l16 = lane & 15, q = l16 >> 2, pp = l16 & 3;
+#pragma unroll
+        for (int f = 0; f < 5; ++f) {
+            const int c = (f < 2 ? wn + 32 * f : wk + 32 * (f - 2)) + cb;
+            const int col = (c & 127) + 4 * pp, ch = col >> 3, sub = (col >> 2) & 1;
+            const int img = f < 2 ? 0 : 1 + (c >> 7);
+            const int r0 = 8 * hh + q, r1 = r0 + 4;
+            fad[2 * f] = lds0 + img * NB_IMG + 256 * r0 + 16 * (ch ^ nt_f(r0)) + 8 * sub;
+            fad[2 * f + 1] = lds0 + img * NB_IMG + 256 * r1 + 16 * (ch ^ nt_f(r1)) + 8 * sub;
+        }
+    }
+    nbf16x8 fa0[2], fb0[3], fa1[2], fb1[3];
+#define GM3D_NB_FRAGS(FA, FB, OFF)                                                                           \
+    _Pragma("unroll") for (int f = 0; f < 5; ++f) {                                                          \
+        const nbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_nbf16x4*)(fad[2 * f] + (OFF)));     \
+        const nbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_nbf16x4*)(fad[2 * f + 1] + (OFF))); \
+        nbf16x8 v;                                                                                           \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }                    \
+        if (f < 2) FA[f] = v; else FB[f - 2] = v;                                                            \
+    }
+#define GM3D_NB_MFMA(FA, FB, I0, I1)                                                                         \
+    _Pragma("unroll") for (int i = I0; i < I1; ++i)                                                          \
+        _Pragma("unroll") for (int j = 0; j < 3; ++j)                                                        \
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);
+
+    GM3D_NB_STAGE(0)
+    if (nst > 1) GM3D_NB_STAGE(1)
+    if (nst > 1) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");         // four pieces per wave and stage: stage 0 landed, stage 1 may be in flight
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (nst > 2) GM3D_NB_STAGE(2)
+    GM3D_NB_FRAGS(fa0, fb0, 0)
+    for (int st = 0; st < nst; ++st) {
+        __builtin_amdgcn_sched_barrier(0);
+        GM3D_NB_MFMA(fa0, fb0, 0, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        GM3D_NB_FRAGS(fa1, fb1, 4096)
+        __builtin_amdgcn_sched_barrier(0);
+        GM3D_NB_MFMA(fa0, fb0, 1, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (st + 1 < nst) {
+            // stage st + 1 landed (this wave's pieces; the barrier covers everybody's); at most stage st + 2's pieces are behind it.
+            // lgkmcnt(0): this wave's reads of stage st are complete before the barrier that lets its buffer be refilled.
+            if (st + 2 < nst) {
+                asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            if (st + 3 < nst) GM3D_NB_STAGE(st + 3)
+            const unsigned step = (st % NB_NBUF == NB_NBUF - 1) ? (unsigned)(-(NB_NBUF - 1) * NB_STAGE) : (unsigned)NB_STAGE;
+#pragma unroll
+            for (int f = 0; f < 10; ++f) fad[f] += step;
+            __builtin_amdgcn_sched_barrier(0);
+            GM3D_NB_MFMA(fa1, fb1, 0, 1)
+            __builtin_amdgcn_sched_barrier(0);
+            GM3D_NB_FRAGS(fa0, fb0, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            GM3D_NB_MFMA(fa1, fb1, 1, 2)
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            GM3D_NB_MFMA(fa1, fb1, 0, 2)
+        }
+    }
+#undef GM3D_NB_FRAGS
+#undef GM3D_NB_MFMA
+#undef GM3D_NB_STAGE
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int n = n0 + wn + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
+                Ob[(size_t)n * ldo + k0 + wk + 32 * j + r] = acc[i][j][g];
+            }
+}
+
 }  // namespace gm3d
+
+// measurement knob: 0 = 128 x 128 tiles everywhere, 1 (default) = 128 x 384 tiles where the shape is a multiple of them
+static int NT_BIG_TILES = 1;
+extern "C" int gm3d_gemm_nt_set_big_tiles(int on) {
+    NT_BIG_TILES = on ? 1 : 0;
+    return GM3D_OK;
+}
+static bool nt_big(int N, int K) { return NT_BIG_TILES && N % 128 == 0 && K % 384 == 0; }
 
 extern "C" int gm3d_gemm_nt_splits(int batch, int R, int N, int K) {
     // the smallest power-of-two row split (<= 64, gm3d_sum_few_rows' limit) that offers the chip >= 400 workgroups (tools/wgrad_split_sweep.py: the optimum sits at 400-600) while every
     // split keeps >= 512 rows (16 stages)
     if (batch < 1 || R < 1 || N < 1 || K < 1) return 1;
+    if (nt_big(N, K)) {
+        // one 512-thread workgroup per CU: the smallest split that offers >= 224 of them, every split >= 256 rows (8 stages)
+        const long long tiles = (long long)batch * (N / 128) * (K / 384);
+        int s = 1;
+        while (tiles * s < 224 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 256) s *= 2;
+        return s;
+    }
     const long long tiles = (long long)batch * (N / 128) * (K / 128);
     int s = 1;
     while (tiles * s < 400 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 512) s *= 2;
@@ -172,6 +332,18 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
     if (((size_t)dY | (size_t)X) & 15) return GM3D_EUNSUPPORTED;
     if (splits > 1 && stride_split < (long long)N * ldo) return GM3D_EINVAL;
     if (batch == 0) return GM3D_OK;
+    if (nt_big(N, K)) {
+        const long long total = (long long)batch * splits * (N / 128) * (K / 384);
+        if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+        const int grid = (int)((total + 7) / 8 * 8);
+        const size_t lds = (size_t)NB_NBUF * NB_STAGE;
+        static LdsAttr attr;
+        if (!attr.ensure((const void*)gemm_nt384_bf16_kernel, lds)) return GM3D_ELAUNCH;
+        hipLaunchKernelGGL(gemm_nt384_bf16_kernel, dim3(grid), dim3(512), lds, (hipStream_t)stream, (const bf16_t*)dY, (const bf16_t*)X, out,
+                           R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, N / 128, K / 384, (int)total);
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
     const long long total = (long long)batch * splits * (N / 128) * (K / 128);
     if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int grid = (int)((total + 7) / 8 * 8);

@@ -268,6 +268,7 @@ def _wgrad_batched_plain(dy, x, out=None):
     return r if out is None else out.copy_(r)
 
 
+WGRAD_MIN_BLOCKS = 5      # stacks with fewer blocks (the 4-block decoders) DEFER their weight-gradient GEMMs to the deep stack's fork point
 _ASYNC_WGRAD = {"stream": None, "used": False, "min_blocks": 5, "deferred": []}
 
 
@@ -287,8 +288,8 @@ class async_wgrad:
     """with async_wgrad(device): <backward>  -- weight-gradient GEMMs of the deep block stacks run on a side stream during the
     region; on exit the current stream waits for it (so whatever follows -- gradient gather, all-reduce, optimizer -- sees them)."""
 
-    def __init__(self, device, min_blocks=5):
-        self.dev, self.min_blocks = torch.device(device), min_blocks
+    def __init__(self, device, min_blocks=None):
+        self.dev, self.min_blocks = torch.device(device), (WGRAD_MIN_BLOCKS if min_blocks is None else min_blocks)
 
     def __enter__(self):
         if ASYNC_WGRAD and self.dev.type == "cuda":

@@ -330,6 +330,10 @@ def wgrad_supported(dy, x):
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and (dy.shape[0] == 1 or (dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)))
 
 
+WGRAD_SPLITS_CAP = 0        # measurement knob: cap on the row splits of the WGRAD_SPLITS_CAP_NB-block stacks' products (0 = none)
+WGRAD_SPLITS_CAP_NB = 4
+
+
 def wgrad_nt(dy, x, out=None, splits=None):
     """out (nb,N,K) f32 = dy[b]^T @ x[b]  (dy (nb,R,N), x (nb,R,K) bf16) -- every weight gradient of a block stack in one launch,
     written into `out` (the parameters' slots of the flat gradient buffer) when given.  Long reductions over few output tiles
@@ -338,6 +342,8 @@ def wgrad_nt(dy, x, out=None, splits=None):
     K = x.shape[2]
     if splits is None:
         splits = lib.gm3d_gemm_nt_splits(nb, R, N, K)
+        if WGRAD_SPLITS_CAP and nb == WGRAD_SPLITS_CAP_NB and R <= 8192:
+            splits = min(splits, WGRAD_SPLITS_CAP)
     if out is None:
         out = torch.empty(nb, N, K, dtype=torch.float32, device=dy.device)
     assert out.dtype == torch.float32 and out.stride(2) == 1 and out.stride(1) >= K

@@ -501,6 +501,11 @@ int gm3d_gemm_nt_bf16(const void *dY, const void *X, float *out, int batch, int 
                       long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split,
                       gm3d_stream_t stream);
 int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
+/* Tile shape of gm3d_gemm_nt_bf16 where (N, K) is a multiple of (128, 384) -- every weight of the transformer blocks: 0 (default) =
+ * 128 x 128 output tiles everywhere, 1 = 128 x 384 tiles (512-thread workgroups, 1.5 x the flops per byte staged from L2, fragment reads
+ * software-pipelined against the MFMAs; measured SLOWER on MI355X, kept as a tested variant).  Results are equal for equal row splits;
+ * gm3d_gemm_nt_splits follows the setting.  Process-wide measurement knob; set before capturing a graph. */
+int gm3d_gemm_nt_set_big_tiles(int on);
 /* Masked multi-head attention of the hierarchical (Point-M2AE) encoder blocks -- SURVEY.md 8f.4; the reference ships only the
  * hyper-parameters (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: dims 96/192/384, 6 heads, local_radius 0.32/0.64/1.28).
  * qkv (B,T,3,H,HD) as the qkv Linear emits it, HD in {16,32,64}, T <= 512; mask (B,T,ceil(T/32)) uint32 bitset, bit (j&31) of

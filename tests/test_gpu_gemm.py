@@ -398,3 +398,27 @@ def test_gemm_weight_stationary_batchnorm_epilogues(groups):
     st = part.double().sum(0)
     assert float((st[:N] - s1).abs().max()) <= 2e-6 * float(y.abs().sum(0).max())
     assert float((st[N:] - s2).abs().max()) <= 2e-6 * float(s2.max())
+
+
+@pytest.mark.parametrize("nb,R,N,K", [(4, 8192, 1536, 384), (12, 3328, 384, 1536), (4, 8192, 384, 384), (2, 2048, 1152, 384), (1, 64, 384, 384)])
+def test_gemm_nt_big_tiles_equal_small_tiles(nb, R, N, K):
+    """128 x 384 output tiles (512-thread workgroups, software-pipelined fragment reads; a measured-slower variant kept behind
+    gm3d_gemm_nt_set_big_tiles) against the 128 x 128 kernel: the same 32-row stages in the same order -> bit-identical slabs for equal
+    row splits, strided operands included."""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib
+    g = torch.Generator(device="cuda").manual_seed(R + N + K)
+    wide = torch.randn(nb, R, N + 64, device="cuda", generator=g).bfloat16()
+    dy = wide[:, :, 64:]
+    x = torch.randn(nb, R, K, device="cuda", generator=g).bfloat16()
+    try:
+        for splits in (1, 2, 4):
+            if R % (32 * splits):
+                continue
+            lib.gm3d_gemm_nt_set_big_tiles(0)
+            small = gemm.wgrad_nt(dy, x, splits=splits)
+            lib.gm3d_gemm_nt_set_big_tiles(1)
+            big = gemm.wgrad_nt(dy, x, splits=splits)
+            assert torch.equal(big, small), splits
+    finally:
+        lib.gm3d_gemm_nt_set_big_tiles(0)

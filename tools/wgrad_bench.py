@@ -37,10 +37,17 @@ shapes = [(12, 3200, 384, 1536), (12, 3200, 1536, 384), (12, 3200, 384, 384), (1
           (1, 262144, 256, 128), (1, 262144, 512, 256), (1, 102400, 384, 512), (1, 8192, 512, 256), (1, 8192, 1024, 384)]
 if __name__ == "__main__":
   print("%-28s %10s %10s %8s   splits" % ("(nb, R, N, K)", "own us", "library us", "ratio"))
+  lib_ = __import__("gm3d_amd._capi", fromlist=["lib"]).lib
   for nb, R, N, K in shapes:
       dy = torch.randn(nb, R, N, device=dev).bfloat16()
       x = torch.randn(nb, R, K, device=dev).bfloat16()
       out = torch.empty(nb, N, K, device=dev)
+      if N % 128 == 0 and K % 384 == 0:
+          lib_.gm3d_gemm_nt_set_big_tiles(1)
+          big = timeit(lambda: gemm.wgrad_nt(dy, x, out))
+          s_big = lib_.gm3d_gemm_nt_splits(nb, R, N, K)
+          lib_.gm3d_gemm_nt_set_big_tiles(0)
+          print("   128x384 tiles %.1f us (%d splits, %.0f TFLOP/s incl. the slab sum)" % (big, s_big, 2.0 * nb * R * N * K / big * 1e-6))
       own = timeit(lambda: gemm.wgrad_nt(dy, x, out))
       was = gemm.OWN_WGRAD
       gemm.OWN_WGRAD = False
