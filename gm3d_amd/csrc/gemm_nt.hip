@@ -297,8 +297,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt384_bf16_kernel(const bf16_t* _
 
 }  // namespace gm3d
 
-// measurement knob: 0 = 128 x 128 tiles everywhere, 1 (default) = 128 x 384 tiles where the shape is a multiple of them
-static int NT_BIG_TILES = 1;
+// measurement knob: 0 (default) = 128 x 128 tiles everywhere, 1 = 128 x 384 tiles where the shape is a multiple of them.
+// Measured (tools/wgrad_tiles.py, kernel only, MI355X): the big tiles reach 530 TFLOP/s where the 128 x 128 kernel reaches 620-790 at
+// the splits the step uses (three 48 KiB workgroups per CU keep more L2 -> LDS bytes in flight than one 96 KiB workgroup does; a
+// 192 x 384 / 8-wave form without the software pipeline reached 800-820 at 8 splits, i.e. with twice the slab-sum traffic) -> off.
+static int NT_BIG_TILES = 0;
 extern "C" int gm3d_gemm_nt_set_big_tiles(int on) {
     NT_BIG_TILES = on ? 1 : 0;
     return GM3D_OK;
