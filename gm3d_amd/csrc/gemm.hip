@@ -33,7 +33,10 @@ constexpr int GSTAGE = (GBM + GBN) * GPITCH;   // bf16 elements per stage
 // scales and shifts each 8-element chunk in registers on its way from global memory to the LDS stage -- models_mae_learn_loss.py's norm1 / norm2 (timm Block, Point-MAE_SA3D/models/Point_MAE.py:128-146) without a pass of
 // their own.  The workgroups of column tile 0 also write the normalised rows (bf16, the weight-gradient GEMM's operand) and the
 // row mean / rstd (the LayerNorm backward's inputs) when asked to.
-template <int KTT, int WMI, bool LNA>
+// RAG (with KTT = 0, plain C (+ bias) output only): ragged shapes -- N and K any multiples of 8 (the 96 / 192 / 288 / 576-wide layers of
+// Point-M2AE).  W rows past N are clamped (their columns are never stored), the last K-stage's chunks past K are replaced by zeros on
+// their way into LDS (the load itself is redirected to the row's last valid chunk: always in bounds), column chunks past N are not stored.
+template <int KTT, int WMI, bool LNA, bool RAG = false>
 __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ C, int M,
                                                               int N, int K, int lda, int ldw, int ldc, int tiles_n,
@@ -92,12 +95,18 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
                 }
             }
         }
-        woff[i] = (size_t)(n0 + row) * ldw + ckc;
+        woff[i] = (size_t)((RAG && n0 + row >= N) ? N - 1 : n0 + row) * ldw + ckc;
     }
+    // RAG: K-stages incl. a partial last one; `dead`: this thread's chunk of the LAST stage lies past K
+    const int KT = KTT > 0 ? KTT : (RAG ? (K + GBK - 1) / GBK : K / GBK);
+    const int klast = (KT - 1) * GBK;
+    const bool dead = RAG && ckc >= K - klast;
+    const int kredir = K - 8 - ckc;                            // column offset that lands this thread on the row's last valid chunk
 #define GM3D_LOAD_STAGE(SET, K0)                                                          \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                       \
-        if (i < ACH) pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + (K0));  \
-        pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + (K0));               \
+        const int ko_ = (RAG && dead && (K0) == klast) ? kredir : (K0);                   \
+        if (i < ACH) pa[SET][i] = *reinterpret_cast<const gbf16x8*>(A + aoff[i] + ko_);   \
+        pw[SET][i] = *reinterpret_cast<const gbf16x8*>(W + woff[i] + ko_);                \
     }                                                                                     \
     if (LNA) {                                                                            \
         pg[SET][0] = *reinterpret_cast<const float4*>(gamma + ckc + (K0));                \
@@ -128,10 +137,19 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
                     *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = hv;           \
                     if (Hout && tile_n == 0 && m0 + row < M)                              \
                         *reinterpret_cast<gbf16x8*>(Hout + (size_t)(m0 + row) * K + (K0) + ckc) = hv;     \
+                } else if (RAG && dead && (K0) == klast) {                                \
+                    gbf16x8 z_;                                                           \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) z_[e] = (bf16_t)0.f;    \
+                    *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = z_;           \
                 } else                                                                    \
                     *reinterpret_cast<gbf16x8*>(as_ + row * GPITCH + ckc) = pa[SET][i];   \
             }                                                                             \
-            *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];           \
+            if (RAG && dead && (K0) == klast) {                                           \
+                gbf16x8 z_;                                                               \
+                _Pragma("unroll") for (int e = 0; e < 8; ++e) z_[e] = (bf16_t)0.f;        \
+                *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = z_;               \
+            } else                                                                        \
+                *reinterpret_cast<gbf16x8*>(ws_ + row * GPITCH + ckc) = pw[SET][i];       \
         }                                                                                 \
     }
 
@@ -143,7 +161,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[i][j][g] = 0.f;
 
-    const int KT = KTT > 0 ? KTT : K / GBK;
     GM3D_LOAD_STAGE(0, 0)
     if (KT > 1) GM3D_LOAD_STAGE(1, GBK)
     GM3D_STORE_STAGE(0, 0, 0)
@@ -227,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_bf16_kernel(const bf16_t* __re
     for (int i = 0; i < 4 * WMI; ++i) {
         const int c = tid + 256 * i;                 // BM rows x 16 chunks of 8 columns
         const int row = c >> 4, nc = (c & 15) * 8;
-        if (m0 + row < M) {
+        if (m0 + row < M && (!RAG || n0 + nc < N)) {
             float v[8];
             const float4 x = *reinterpret_cast<const float4*>(cs + row * GCP + nc), y = *reinterpret_cast<const float4*>(cs + row * GCP + nc + 4);
             v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; v[4] = y.x; v[5] = y.y; v[6] = y.z; v[7] = y.w;
@@ -325,11 +342,13 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
     if (ln && (!ln->stats || !ln->gamma || !ln->beta || K != 384 || (ln->mean && !ln->rstd))) return GM3D_EINVAL;
     if (!A || !W || (!C && !G && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp < N)) return GM3D_EINVAL;
-    if (N % GBN || K % GBK || lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
+    const bool ragged = N % GBN || K % GBK;
+    if (ragged && (ln || G || P || Fpre || !C || N % 8 || K % 8 || K < 8)) return GM3D_EUNSUPPORTED;   // ragged: the plain product only
+    if (lda % 8 || ldw % 8 || lda < K || ldw < K) return GM3D_EUNSUPPORTED;
     if ((C && (ldc % 8 || ldc < N)) || (G && (ldg % 8 || ldg < N))) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
     const int bm = ln ? 64 : gemm_tile_height(M);     // LayerNorm-on-load: 64-row tiles (the 128-row form runs out of registers)
-    const int tiles_m = (M + bm - 1) / bm, tiles_n = N / GBN;
+    const int tiles_m = (M + bm - 1) / bm, tiles_n = (N + GBN - 1) / GBN;
     if ((long long)tiles_m * tiles_n > 0x7fffffffLL) return GM3D_EUNSUPPORTED;
     const size_t lds_ab = (size_t)2 * (bm + GBN) * GPITCH * sizeof(bf16_t), lds_c = (size_t)bm * GCP * sizeof(float);
     const size_t lds = lds_ab > lds_c ? lds_ab : lds_c;
@@ -345,6 +364,21 @@ static int gemm_launch(const void* A, const void* W, const float* bias, void* C,
                            ln ? ln->eps : 0.f, ln ? (bf16_t*)ln->H : nullptr, ln ? ln->mean : nullptr, ln ? ln->rstd : nullptr); \
     }
 #define GM3D_GEMM_LAUNCH(KTT, WMI) GM3D_GEMM_LAUNCH_(KTT, WMI, false)
+    if (ragged) {
+#define GM3D_GEMM_RAG(WMI)                                                                                                    \
+    {                                                                                                                         \
+        static LdsAttr attr;                                                                                                  \
+        if (!attr.ensure((const void*)gemm_tn_bf16_kernel<0, WMI, false, true>, lds)) return GM3D_ELAUNCH;                    \
+        hipLaunchKernelGGL((gemm_tn_bf16_kernel<0, WMI, false, true>), dim3(grid), dim3(256), lds, (hipStream_t)stream,       \
+                           (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, K, lda, ldw, ldc, tiles_n, total,      \
+                           nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f,  \
+                           nullptr, nullptr, nullptr);                                                                        \
+    }
+        if (bm == 64) GM3D_GEMM_RAG(1) else GM3D_GEMM_RAG(2)
+#undef GM3D_GEMM_RAG
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
     if (ln) {       // K = 384: six stages
         GM3D_GEMM_LAUNCH_(6, 1, true)
         GM3D_CHECK_LAUNCH();

@@ -61,7 +61,7 @@ __device__ __forceinline__ nbf16x8 nt_frag(const unsigned char* img, int kk0, in
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
                                                               float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
                                                               long long sY, long long sX, long long sO, long long sOs, int splits,
-                                                              int tiles_n, int tiles_k, int total) {
+                                                              int tiles_n, int tiles_k, int total, int Nfull, int Kfull) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -83,12 +83,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
     const int prow = lane >> 4, pcs = lane & 15;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)nsm;
     size_t yoff[2], xoff[2];
+    // ragged N / K (multiples of 8: the 96 / 192 / 288 / 576-wide layers of Point-M2AE): chunks past the matrix edge are redirected to
+    // the tile's last valid chunk (in bounds; they only feed output elements that are never stored)
+    const int vy = (Nfull - n0) / 8 < 16 ? (Nfull - n0) / 8 : 16, vx = (Kfull - k0) / 8 < 16 ? (Kfull - k0) / 8 : 16;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int row = 4 * (w + 4 * i) + prow;                    // row inside the stage's 32
         const int ch = pcs ^ nt_f(row);                            // the chunk that belongs at LDS slot pcs of this row
-        yoff[i] = (size_t)row * ldy + ch * 8;
-        xoff[i] = (size_t)row * ldx + ch * 8;
+        yoff[i] = (size_t)row * ldy + (ch < vy ? ch : vy - 1) * 8;
+        xoff[i] = (size_t)row * ldx + (ch < vx ? ch : vx - 1) * 8;
     }
 #define GM3D_NT_STAGE(ST)                                                                                    \
     {                                                                                                        \
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int n = n0 + wn + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
-                Ob[(size_t)n * ldo + k0 + wk + 32 * j + r] = acc[i][j][g];
+                if (n < Nfull && k0 + wk + 32 * j + r < Kfull) Ob[(size_t)n * ldo + k0 + wk + 32 * j + r] = acc[i][j][g];
             }
 }
 
@@ -319,7 +322,7 @@ extern "C" int gm3d_gemm_nt_splits(int batch, int R, int N, int K) {
         while (tiles * s < 224 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 256) s *= 2;
         return s;
     }
-    const long long tiles = (long long)batch * (N / 128) * (K / 128);
+    const long long tiles = (long long)batch * ((N + 127) / 128) * ((K + 127) / 128);
     int s = 1;
     while (tiles * s < 400 && s < 64 && R % (64 * s) == 0 && R / (2 * s) >= 512) s *= 2;
     return s;
@@ -330,7 +333,7 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
                                  gm3d_stream_t stream) {
     using namespace gm3d;
     if (!dY || !X || !out || batch < 0 || R < 1 || N < 1 || K < 1 || splits < 1) return GM3D_EINVAL;
-    if (N % 128 || K % 128 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldo < K) return GM3D_EUNSUPPORTED;
+    if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldo < K) return GM3D_EUNSUPPORTED;   // ragged N / K: multiples of 8
     if (R % (NT_BR * splits)) return GM3D_EUNSUPPORTED;
     if (((size_t)dY | (size_t)X) & 15) return GM3D_EUNSUPPORTED;
     if (splits > 1 && stride_split < (long long)N * ldo) return GM3D_EINVAL;
@@ -347,14 +350,15 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
         GM3D_CHECK_LAUNCH();
         return GM3D_OK;
     }
-    const long long total = (long long)batch * splits * (N / 128) * (K / 128);
+    const int tn_ = (N + 127) / 128, tk_ = (K + 127) / 128;
+    const long long total = (long long)batch * splits * tn_ * tk_;
     if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     const int grid = (int)((total + 7) / 8 * 8);
     const size_t lds = (size_t)NT_NBUF * NT_STAGE;
     static LdsAttr attr;
     if (!attr.ensure((const void*)gemm_nt_bf16_kernel, lds)) return GM3D_ELAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dY, (const bf16_t*)X, out,
-                       R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, N / 128, K / 128, (int)total);
+                       R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, tn_, tk_, (int)total, N, K);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -22,6 +22,17 @@ def supported(x, w):
             and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
 
 
+RAGGED = True            # widths that are multiples of 8 but not of the tiles (Point-M2AE's 96 / 192 / 288 / 576) on our own kernels
+
+
+def ragged_supported(x, w):
+    """the plain product on csrc/gemm.hip's ragged form: N, K any multiples of 8 (W rows past N clamped, the last K-stage zero-filled)."""
+    return (ENABLED and RAGGED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
+            and x.shape[1] == w.shape[1] and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0 and w.shape[1] >= 8 and x.stride(1) == 1
+            and w.stride(1) == 1 and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.stride(0) >= x.shape[1]
+            and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
+
+
 def linear_tn(x, w, bias=None, out=None):
     """x (M,K) bf16, w (N,K) bf16, bias (N) f32 or None -> (M,N) bf16 = x @ w^T + bias (fp32 accumulate, one rounding)."""
     M, K = x.shape
@@ -255,6 +266,11 @@ def mm(x, w, bias=None, out=None):
     """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names.  Operands that do not meet the hand-written kernels' layout
     rules (fp32 parity mode, odd widths) go to torch.mm: never on the bf16 step's path (tools/leftover_sites.py lists none)."""
     how = choose(x.shape[0], w.shape[0], w.shape[1]) if supported(x, w) else "lib"
+    if how == "lib" and ragged_supported(x, w) and (out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0)):
+        # a ragged last column tile alone (K a multiple of the 64-column stage): the ring kernel; a ragged K as well: csrc/gemm.hip
+        if w.shape[1] % 64 == 0:
+            return linear_tn_ring(x, w, bias, out)
+        return linear_tn(x, w, bias, out)
     if how != "lib" and ws_supported(x, w):
         return linear_tn_ws(x, w, bias, out)
     if how == "own":
@@ -286,9 +302,9 @@ def mm_nn(x, w, out=None):
     run as the TN product against a transposed copy of w (one small transposing launch per call: the weights of the layers this
     serves have 32 K .. 512 K elements); anything else goes to torch.mm."""
     if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
-            and w.shape[1] % 128 == 0 and w.shape[0] % 64 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
+            and w.shape[1] % 8 == 0 and w.shape[0] % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
         wt = transposed(w.contiguous())
-        if supported(x, wt):
+        if supported(x, wt) or ragged_supported(x, wt):
             return mm(x, wt, None, out)
     y = x @ w
     return y if out is None else out.copy_(y)
@@ -323,9 +339,10 @@ OWN_WGRAD = True          # weight-gradient (NT) GEMMs on the hand-written kerne
 
 
 def wgrad_supported(dy, x):
-    """dy (nb,R,N), x (nb,R,K) bf16 with unit inner stride and a common batch layout; N, K % 128 == 0, R % 32 == 0."""
+    """dy (nb,R,N), x (nb,R,K) bf16 with unit inner stride and a common batch layout; N, K % 8 == 0 (ragged edge tiles), R % 32 == 0."""
+    edge = 8 if RAGGED else 128
     return (ENABLED and OWN_WGRAD and dy.is_cuda and dy.dtype == torch.bfloat16 and x.dtype == torch.bfloat16 and dy.dim() == 3
-            and x.dim() == 3 and dy.shape[:2] == x.shape[:2] and dy.shape[2] % 128 == 0 and x.shape[2] % 128 == 0
+            and x.dim() == 3 and dy.shape[:2] == x.shape[:2] and dy.shape[2] % edge == 0 and x.shape[2] % edge == 0
             and dy.shape[1] % 32 == 0 and dy.stride(2) == 1 and x.stride(2) == 1 and dy.stride(1) % 8 == 0 and x.stride(1) % 8 == 0
             and dy.data_ptr() % 16 == 0 and x.data_ptr() % 16 == 0 and (dy.shape[0] == 1 or (dy.stride(0) % 8 == 0 and x.stride(0) % 8 == 0)))
 

@@ -53,6 +53,8 @@ class LinearBiasFn(torch.autograd.Function):
                 y = gemm.mm(x2, W, _c32(b) if b is not None else None)
             elif _ragged_ok(x2, W):
                 y = gemm.linear_tn_ring(x2, W, _c32(b) if b is not None else None)
+            elif gemm.ragged_supported(x2, W):         # ragged K as well (K = 96): csrc/gemm.hip's ragged form
+                y = gemm.linear_tn(x2, W, _c32(b) if b is not None else None)
             else:
                 y = torch.addmm(weight_cache.get(b, adt), x2, W.t()) if b is not None else x2 @ W.t()
             ctx.save_for_backward(x2, w)

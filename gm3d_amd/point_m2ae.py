@@ -232,15 +232,19 @@ class BlockStack(nn.Module):
         adt = heads._adt()
         B = x.shape[0]
         s, y, yb, rs = x, None, None, None
+        # the DropPath factors of the whole stack (two sites per block) from ONE uniform draw + one launch, not four launches per site
+        probs = []
         for blk in self.blocks:
             p = blk.drop_path.drop_prob if isinstance(blk.drop_path, M.DropPath) else 0.0
+            probs += [p, p]
+        scales = M.drop_path_scales(B, probs, self.training, x.device)
+        for i, blk in enumerate(self.blocks):
             s, h = heads.AddLayerNormFn.apply(s, y, yb, rs, pos, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, adt)
             a = blk.attn(h, bits, proj_bias=False)
-            rs1 = M.drop_path_scale(B, p, blk.training, x.device)
-            s, h = heads.AddLayerNormFn.apply(s, a, blk.attn.proj.bias, rs1, None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, adt)
+            s, h = heads.AddLayerNormFn.apply(s, a, blk.attn.proj.bias, scales[2 * i], None, blk.norm2.weight, blk.norm2.bias, blk.norm2.eps, adt)
             g = heads.BiasGeluFn.apply(_linear(h, blk.mlp.fc1.weight, None), blk.mlp.fc1.bias, adt)
             y, yb = _linear(g, blk.mlp.fc2.weight, None), blk.mlp.fc2.bias
-            rs = M.drop_path_scale(B, p, blk.training, x.device)
+            rs = scales[2 * i + 1]
         return heads.ResidualTailFn.apply(s, y, yb, rs, adt)
 
 

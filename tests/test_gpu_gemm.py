@@ -422,3 +422,49 @@ def test_gemm_nt_big_tiles_equal_small_tiles(nb, R, N, K):
             assert torch.equal(big, small), splits
     finally:
         lib.gm3d_gemm_nt_set_big_tiles(0)
+
+
+@pytest.mark.parametrize("M,K,N", [(65536, 96, 288), (8192, 96, 96), (3000, 288, 96), (4096, 96, 384), (200, 40, 72), (8192, 192, 576), (333, 8, 8),
+                                   (5000, 576, 192), (64, 96, 128)])
+def test_gemm_ragged_shapes_on_the_register_prefetch_kernel(M, K, N):
+    """csrc/gemm.hip's ragged form (N, K multiples of 8: Point-M2AE's 96 / 192 / 288 / 576-wide layers): W rows past N clamped, the last
+    K-stage zero-filled, column chunks past N not stored -- against an fp32 product of the same bf16 operands (fp32 accumulation, one
+    rounding), with and without bias, nothing written outside the (M,N) block of a wider destination; gemm.mm / mm_nn route here."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(M + K + N)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g)
+    assert gemm.ragged_supported(x, w)
+    for bias in (None, b):
+        want = x.float() @ w.float().t() + (bias if bias is not None else 0.0)
+        wide = torch.full((M + 2, N + 8), 7.0, device="cuda", dtype=torch.bfloat16)
+        gemm.linear_tn(x, w, bias, out=wide[:M, :N])
+        err = float((wide[:M, :N].float() - want).abs().max())
+        assert err <= 1e-2 * max(1.0, float(want.abs().max())), err
+        assert bool((wide[M:] == 7.0).all()) and bool((wide[:, N:] == 7.0).all())
+        got = gemm.mm(x, w, bias)
+        assert float((got.float() - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max()))
+    wt = w.t().contiguous()                     # (K,N): mm_nn(x, wt) = x @ wt
+    got = gemm.mm_nn(x, wt)
+    want = x.float() @ wt.float()
+    assert float((got.float() - want).abs().max()) <= 1e-2 * max(1.0, float(want.abs().max()))
+
+
+@pytest.mark.parametrize("nb,R,N,K", [(1, 65536, 288, 96), (3, 2048, 96, 96), (1, 8192, 96, 384), (2, 4096, 576, 192), (1, 64, 8, 8), (1, 32768, 192, 768)])
+def test_gemm_nt_ragged_edges(nb, R, N, K):
+    """The weight-gradient kernel with N, K any multiples of 8 (edge tiles read clamped chunks and store only what exists) against an
+    fp32 product; the rows of a wider destination beyond (N,K) stay untouched; deterministic."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(R + N + K)
+    dy = torch.randn(nb, R, N, device="cuda", generator=g).bfloat16()
+    x = torch.randn(nb, R, K, device="cuda", generator=g).bfloat16()
+    assert gemm.wgrad_supported(dy, x)
+    want = torch.bmm(dy.float().transpose(1, 2), x.float())
+    got = gemm.wgrad_nt(dy, x)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max()) * max(1.0, (R / 4096) ** 0.5)
+    assert torch.equal(got, gemm.wgrad_nt(dy, x))
+    flat = torch.full((nb * N * K + 256,), 3.0, device="cuda")
+    out = flat[128:128 + nb * N * K].view(nb, N, K)
+    gemm.wgrad_nt(dy, x, out)
+    assert torch.equal(out, got) and bool((flat[:128] == 3.0).all()) and bool((flat[128 + nb * N * K:] == 3.0).all())

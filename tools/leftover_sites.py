@@ -39,6 +39,27 @@ class Sites(TorchDispatchMode):
 
 dev = torch.device("cuda")
 torch.manual_seed(0)
+if "--m2ae" in sys.argv:          # the Point-M2AE step instead (python tools/leftover_sites.py --m2ae)
+    from gm3d_amd import point_m2ae as P
+    model = P.PointM2AE().to(dev).train()
+    ema = E.ModelEma(model, 0.999)
+    opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
+    x0 = make_clouds(int(os.environ.get("B", 128)), 2048, 1, dev)
+    args = SimpleNamespace(bf16=True, epochs=300)
+    for _ in range(2):
+        P.pretrain_step(model, ema, opt, x0.clone(), 100, args)
+    torch.cuda.synchronize()
+    with Sites() as s:
+        P.pretrain_step(model, ema, opt, x0.clone(), 100, args)
+    torch.cuda.synchronize()
+    print("aten ops with a CUDA result (GEMMs included): %d" % sum(s.sites.values()))
+    agg = collections.Counter()
+    for (site, op, shape), n in s.sites.items():
+        agg[(site, op)] += n
+    for (site, op), n in sorted(agg.items(), key=lambda kv: -kv[1])[:70]:
+        shapes = sorted({tuple(sh) for (st, o, sh) in s.sites if st == site and o == op})[:3]
+        print("%3d  %-34s %-26s %s" % (n, site, op, shapes))
+    sys.exit(0)
 model = M.mae_vit_base_patch16_dec512d8b().to(dev).train()
 ema = E.ModelEma(model, 0.9999)
 opt = E.build_optimizer(model, lr=1e-3, weight_decay=0.05, flat=True, model_ema=ema)
