@@ -925,7 +925,7 @@ extern "C" int gm3d_embed_partial_rows(int kind, int n, int C) {
     using namespace gm3d;
     if (kind == 0) return moments_grid(n);        // moments3: n = rows
     if (kind == 1) return group_grid(n);          // (G,K,C) kernels: n = groups
-    if (kind == 3) { int g = (n + 7) / 8; return g > 1024 ? 1024 : (g < 1 ? 1 : g); }   // gm3d_pn_layer1_bwd_stats
+    if (kind == 3) { const int sl = C > 256 ? 4 : 8; int g = (n + sl - 1) / sl; return g > 1024 ? 1024 : (g < 1 ? 1 : g); }   // gm3d_lin3_gelu_bwd (8 row slices per workgroup, 4 for C > 256)
     return row_grid(n, C);                        // (R,C) kernels: n = rows
 }
 
@@ -1255,9 +1255,9 @@ extern "C" int gm3d_lin3_gelu_bwd(const void* dout, const float* x, const float*
                                   double* partial, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
     if (!dout || !x || !w || !b || !partial || R < 1) return GM3D_EINVAL;
-    if (!chan_ok(C) || C > 256) return GM3D_EUNSUPPORTED;
+    if (!chan_ok(C) || C > 512) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
-    const int tpr = C / 8, sl = 8;
+    const int tpr = C / 8, sl = C > 256 ? 4 : 8;       // C = 384: 192 threads, 48 KiB of fp64 partials
     const size_t lds = (size_t)sl * 4 * C * sizeof(double);
     int grid = (R + sl - 1) / sl; grid = grid > 1024 ? 1024 : grid;
     hipStream_t st = (hipStream_t)stream;

@@ -34,6 +34,7 @@ from .hierarchical_group import HierarchicalGroup
 
 FUSED_EMBED0 = True
 FUSED_LAYERNORM = True
+FUSED_POS = True          # positional MLPs through heads.PosEmbedFn (tests flip it)
 FUSED_BLOCKS = True       # block stacks: residual sums inside the LayerNorm kernel, bias + GELU as one pass, biases of proj / fc2 added
 #                           (and their gradients summed) by the LayerNorm kernels -- heads.AddLayerNormFn / BiasGeluFn; any width
 ACT_TAPS = None           # tests set this to a list: the sign pattern (pre-activation > 0) of every ReLU / LeakyReLU of a grad-enabled
@@ -280,6 +281,15 @@ def _pos_mlp(dim):
     return nn.Sequential(Linear(3, dim), nn.GELU(), Linear(dim, dim))
 
 
+def _pos(mlp, centers):
+    """a positional MLP Linear(3,C) -> GELU -> Linear(C,C) on (B,G,3) centres.  GPU: the north-star model's fused node
+    (heads.PosEmbedFn: the K = 3 layer + GELU as one streaming kernel, its backward a pure reduction, the C x C layer on our GEMM)."""
+    if FUSED_POS and centers.is_cuda and centers.dim() == 3 and mlp[0].out_features % 8 == 0:
+        from . import heads
+        return heads.PosEmbedFn.apply(centers, mlp[0].weight, mlp[0].bias, mlp[2].weight, mlp[2].bias, heads._adt())
+    return mlp(centers)
+
+
 class PointM2AE(nn.Module):
     """config: the `model` section of cfgs/config_Point_M2AE.yaml (dict or attribute object)."""
 
@@ -345,7 +355,7 @@ class PointM2AE(nn.Module):
             vis = ~masks[i]
             with torch.no_grad():       # == pack_mask(~(vis_i & vis_j) | radius_mask(centres)), one launch
                 bits = ops.radius_mask_bits(centers[i], vis, self.local_radius[i])
-            pos = self.encoder_pos_embeds[i](centers[i])
+            pos = _pos(self.encoder_pos_embeds[i], centers[i])
             y = self.encoder_blocks[i](tok, pos.to(tok.dtype), bits)
             outs.append(y)
             prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
@@ -370,7 +380,7 @@ class PointM2AE(nn.Module):
         else:
             mtok = self.mask_token.to(x2.dtype).expand(B, self.num_group, -1)
         xc = torch.where(vis2.unsqueeze(-1), x2, mtok)
-        xc = self.h_decoder[0](xc, self.decoder_pos_embeds[0](centers[2]).to(xc.dtype))
+        xc = self.h_decoder[0](xc, _pos(self.decoder_pos_embeds[0], centers[2]).to(xc.dtype))
         h = self.loss_pred_head
         if xc.is_cuda:
             # the north-star model's fused head (heads.LossPredHeadFn): its reductions are our own kernels -- the bias gradient in
@@ -388,7 +398,7 @@ class PointM2AE(nn.Module):
         x1 = self.encoder_norms[1](enc[1])
         x1 = torch.where(vis1.unsqueeze(-1), x1, torch.zeros((), dtype=x1.dtype, device=x1.device))
         x1 = self.token_prop[0](centers[1], centers[2], x1, xc)
-        x1 = self.h_decoder[1](x1, self.decoder_pos_embeds[1](centers[1]).to(x1.dtype))
+        x1 = self.h_decoder[1](x1, _pos(self.decoder_pos_embeds[1], centers[1]).to(x1.dtype))
         x1 = self.decoder_norm(x1)
         G1, k1 = neighborhoods[1].shape[1], neighborhoods[1].shape[2]
         rec = _linear(x1, self.rec_head.weight, self.rec_head.bias).view(B, G1, k1, 3)

@@ -301,7 +301,7 @@ int gm3d_colsum_partial_w(const void *m, const float *roww, int R, int C, float 
 int gm3d_lin3_gelu_fwd(const float *x, const float *w, const float *b, void *out, int R, int C, int dtype,
                        gm3d_stream_t stream);
 /* its backward reductions: dpre = dout * GELU'(pre); partial[row][q][c] fp64, q = 0: sum dpre, 1..3: sum dpre * x_j;
- * rows = gm3d_embed_partial_rows(3, R, C); C <= 256. */
+ * rows = gm3d_embed_partial_rows(3, R, C); C <= 512. */
 int gm3d_lin3_gelu_bwd(const void *dout, const float *x, const float *w, const float *b, int R, int C,
                        double *partial, int dtype, gm3d_stream_t stream);
 
