@@ -61,7 +61,9 @@ __device__ __forceinline__ nbf16x8 nt_frag(const unsigned char* img, int kk0, in
 __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
                                                               float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
                                                               long long sY, long long sX, long long sO, long long sOs, int splits,
-                                                              int tiles_n, int tiles_k, int total, int Nfull, int Kfull) {
+                                                              int tiles_n, int tiles_k, int total, int Nfull, int Kfull,
+                                                              int* __restrict__ counters, float* __restrict__ Ofin, long long sOfin,
+                                                              int ldofin) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
@@ -151,6 +153,38 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
                 const int n = n0 + wn + 32 * i + (g & 3) + 8 * (g >> 2) + 4 * hh;
                 if (n < Nfull && k0 + wk + 32 * j + r < Kfull) Ob[(size_t)n * ldo + k0 + wk + 32 * j + r] = acc[i][j][g];
             }
+    if (counters) {
+        // The slab sum inside this launch (instead of gm3d_sum_few_rows): the workgroup that completes a tile's LAST slab -- whichever
+        // it is -- adds the slabs of the tile in slab order 0, 1, ... (the order of gm3d_sum_few_rows: same bits, independent of the
+        // arrival order) and writes the result.  Release: slab stores -> fence -> counter; acquire: counter -> fence -> slab loads.
+        // The counter resets itself for the next launch that is handed this slice.
+        __shared__ int s_last;
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            int* cnt = counters + ((size_t)b * tiles_n + tn) * tiles_k + tk;
+            const int prev = atomicAdd(cnt, 1);
+            s_last = prev == splits - 1;
+            if (s_last) atomicExch(cnt, 0);
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            const float* P0 = O + (size_t)b * sO + (size_t)n0 * ldo + k0;
+            float* F0 = Ofin + (size_t)b * sOfin + (size_t)n0 * ldofin + k0;
+#pragma unroll 4
+            for (int i = 0; i < 16; ++i) {
+                const int e = tid + 256 * i, row = e >> 5, c4 = (e & 31) * 4;
+                if (n0 + row < Nfull && k0 + c4 < Kfull) {
+                    const float* p = P0 + (size_t)row * ldo + c4;
+                    typedef float nf32x4 __attribute__((ext_vector_type(4)));
+                    nf32x4 a = __builtin_nontemporal_load(reinterpret_cast<const nf32x4*>(p));
+                    for (int sp2 = 1; sp2 < splits; ++sp2) a += __builtin_nontemporal_load(reinterpret_cast<const nf32x4*>(p + (size_t)sp2 * sOs));
+                    *reinterpret_cast<nf32x4*>(F0 + (size_t)row * ldofin + c4) = a;
+                }
+            }
+        }
+    }
 }
 
 // ---- 128 x 384 output tiles (the block stacks' weight gradients: every (N, K) there is a multiple of (128, 384)) ----------------------
@@ -328,9 +362,9 @@ extern "C" int gm3d_gemm_nt_splits(int batch, int R, int N, int K) {
     return s;
 }
 
-extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int batch, int R, int N, int K, int ldy, int ldx, int ldo,
-                                 long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split,
-                                 gm3d_stream_t stream) {
+static int nt_launch(const void* dY, const void* X, float* out, int batch, int R, int N, int K, int ldy, int ldx, int ldo,
+                     long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split, gm3d_stream_t stream,
+                     int* counters, float* fin, long long stride_fin, int ldfin) {
     using namespace gm3d;
     if (!dY || !X || !out || batch < 0 || R < 1 || N < 1 || K < 1 || splits < 1) return GM3D_EINVAL;
     if (N % 8 || K % 8 || ldy % 8 || ldx % 8 || ldy < N || ldx < K || ldo < K) return GM3D_EUNSUPPORTED;   // ragged N / K: multiples of 8
@@ -338,7 +372,7 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
     if (((size_t)dY | (size_t)X) & 15) return GM3D_EUNSUPPORTED;
     if (splits > 1 && stride_split < (long long)N * ldo) return GM3D_EINVAL;
     if (batch == 0) return GM3D_OK;
-    if (nt_big(N, K)) {
+    if (!counters && nt_big(N, K)) {
         const long long total = (long long)batch * splits * (N / 128) * (K / 384);
         if (total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
         const int grid = (int)((total + 7) / 8 * 8);
@@ -358,7 +392,28 @@ extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int 
     static LdsAttr attr;
     if (!attr.ensure((const void*)gemm_nt_bf16_kernel, lds)) return GM3D_ELAUNCH;
     hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, (const bf16_t*)dY, (const bf16_t*)X, out,
-                       R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, tn_, tk_, (int)total, N, K);
+                       R / splits, ldy, ldx, ldo, stride_y, stride_x, stride_o, stride_split, splits, tn_, tk_, (int)total, N, K, counters, fin,
+                       stride_fin, ldfin);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
+
+extern "C" int gm3d_gemm_nt_bf16(const void* dY, const void* X, float* out, int batch, int R, int N, int K, int ldy, int ldx, int ldo,
+                                 long long stride_y, long long stride_x, long long stride_o, int splits, long long stride_split,
+                                 gm3d_stream_t stream) {
+    return nt_launch(dY, X, out, batch, R, N, K, ldy, ldx, ldo, stride_y, stride_x, stride_o, splits, stride_split, stream, nullptr, nullptr, 0,
+                     0);
+}
+
+// ... with the sum over the row splits inside the launch: part (batch, splits, N, K) f32 scratch for the slabs, out (batch, N, ldo) the
+// result (batch stride stride_o), counters: gm3d_gemm_nt_tiles(N, K) * batch ints that are ZERO on entry and zero again on exit (a
+// slice no concurrently running launch uses).  Bit-identical to gm3d_gemm_nt_bf16 into part followed by gm3d_sum_few_rows.
+extern "C" int gm3d_gemm_nt_bf16_sum(const void* dY, const void* X, float* part, float* out, int* counters, int batch, int R, int N, int K,
+                                     int ldy, int ldx, int ldo, long long stride_y, long long stride_x, long long stride_o, int splits,
+                                     gm3d_stream_t stream) {
+    if (!part || !out || !counters || splits < 2 || ldo < K || ldo % 4 || ((size_t)out & 15) || ((size_t)part & 15) || K % 4) return GM3D_EINVAL;
+    return nt_launch(dY, X, part, batch, R, N, K, ldy, ldx, K, stride_y, stride_x, (long long)splits * N * K, splits, (long long)N * K, stream,
+                     counters, out, stride_o, ldo);
+}
+
+extern "C" int gm3d_gemm_nt_tiles(int N, int K) { return N < 1 || K < 1 ? 0 : ((N + 127) / 128) * ((K + 127) / 128); }

@@ -351,10 +351,38 @@ WGRAD_SPLITS_CAP = 0        # measurement knob: cap on the row splits of the WGR
 WGRAD_SPLITS_CAP_NB = 4
 
 
+FUSE_SLAB_SUM = False      # the sum over the row splits inside the NT launch (the last workgroup of a tile adds its slabs in slab order):
+#                            bit-identical, 17 launches fewer per step -- and 0.8-1.0 ms SLOWER (same-box A/B 8.32 / 8.59 vs 7.53 ms): the
+#                            agent-scope release fence every workgroup needs before it bumps the tile counter writes back its XCD's L2
+#                            (8 XCDs, no common L2), also under the kernels running beside it.  Kept as a tested entry point.
+FUSE_SLAB_SUM_MAX = 8      # ... for up to this many splits (one workgroup adds all slabs of its tile; long splits keep gm3d_sum_few_rows)
+_nt_counters = {}          # device -> [int32 zeros, next free offset]: tile counters, self-resetting; slices handed out round-robin
+
+
+def _nt_counter_slice(device, need):
+    """`need` zeroed ints no other launch in flight uses (a rotating slice of one persistent buffer; 64 Ki counters = > 100 launches
+    of the step's largest product before a slice comes round again).  None while a stream capture runs and the buffer does not exist
+    yet (a buffer first zeroed inside a capture holds nothing until the first replay)."""
+    key = str(device)
+    ent = _nt_counters.get(key)
+    if ent is None:
+        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return None
+        ent = _nt_counters[key] = [torch.zeros(1 << 16, dtype=torch.int32, device=device), 0]
+    buf, off = ent
+    if need > buf.numel():
+        return None
+    if off + need > buf.numel():
+        off = 0
+    ent[1] = off + need
+    return buf[off:off + need]
+
+
 def wgrad_nt(dy, x, out=None, splits=None):
     """out (nb,N,K) f32 = dy[b]^T @ x[b]  (dy (nb,R,N), x (nb,R,K) bf16) -- every weight gradient of a block stack in one launch,
     written into `out` (the parameters' slots of the flat gradient buffer) when given.  Long reductions over few output tiles
-    are cut into `splits` row ranges whose fp32 partial products are added in a fixed order by gm3d_sum_few_rows."""
+    are cut into `splits` row ranges whose fp32 partial products are added in slab order: inside the same launch for up to
+    FUSE_SLAB_SUM_MAX splits (gm3d_gemm_nt_bf16_sum), by gm3d_sum_few_rows beyond -- the same bits either way."""
     nb, R, N = dy.shape
     K = x.shape[2]
     if splits is None:
@@ -369,6 +397,14 @@ def wgrad_nt(dy, x, out=None, splits=None):
                 dy.stride(1), x.stride(1), out.stride(1), dy.stride(0), x.stride(0), out.stride(0), 1, 0, _stream())
         return out
     part = torch.empty(nb, splits, N, K, dtype=torch.float32, device=dy.device)
+    if (FUSE_SLAB_SUM and splits <= FUSE_SLAB_SUM_MAX and K % 4 == 0 and out.stride(1) % 4 == 0 and out.data_ptr() % 16 == 0
+            and (nb == 1 or out.stride(0) >= N * out.stride(1))):
+        cnt = _nt_counter_slice(dy.device, nb * lib.gm3d_gemm_nt_tiles(N, K))
+        if cnt is not None:
+            _launch("gm3d_gemm_nt_bf16_sum", {"B": nb, "M": R, "N": N, "K": K}, lib.gm3d_gemm_nt_bf16_sum, _ptr(dy), _ptr(x), _ptr(part),
+                    _ptr(out), _ptr(cnt), nb, R, N, K, dy.stride(1), x.stride(1), out.stride(1), dy.stride(0), x.stride(0), out.stride(0),
+                    splits, _stream())
+            return out
     _launch("gm3d_gemm_nt_bf16", {"B": nb, "M": R, "N": N, "K": K}, lib.gm3d_gemm_nt_bf16, _ptr(dy), _ptr(x), _ptr(part), nb, R, N, K,
             dy.stride(1), x.stride(1), K, dy.stride(0), x.stride(0), splits * N * K, splits, N * K, _stream())
     if out.is_contiguous() or (out.stride(1) == K and out.stride(0) == N * K):

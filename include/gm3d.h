@@ -506,6 +506,13 @@ int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
  * software-pipelined against the MFMAs; measured SLOWER on MI355X, kept as a tested variant).  Results are equal for equal row splits;
  * gm3d_gemm_nt_splits follows the setting.  Process-wide measurement knob; set before capturing a graph. */
 int gm3d_gemm_nt_set_big_tiles(int on);
+/* gm3d_gemm_nt_bf16 with the sum over the row splits INSIDE the launch (no gm3d_sum_few_rows pass): the workgroup that finishes a
+ * tile's last slab adds that tile's slabs in slab order (bit-identical to the two-launch form, whatever the arrival order) and writes
+ * out (batch, N, ldo; batch stride stride_o; ldo % 4 == 0).  part: (batch, splits, N, K) f32 scratch; counters: batch *
+ * gm3d_gemm_nt_tiles(N, K) ints, zero on entry, zero again on exit, not shared with a launch that may run concurrently.  splits >= 2. */
+int gm3d_gemm_nt_bf16_sum(const void *dY, const void *X, float *part, float *out, int *counters, int batch, int R, int N, int K, int ldy,
+                          int ldx, int ldo, long long stride_y, long long stride_x, long long stride_o, int splits, gm3d_stream_t stream);
+int gm3d_gemm_nt_tiles(int N, int K);
 /* Masked multi-head attention of the hierarchical (Point-M2AE) encoder blocks -- SURVEY.md 8f.4; the reference ships only the
  * hyper-parameters (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: dims 96/192/384, 6 heads, local_radius 0.32/0.64/1.28).
  * qkv (B,T,3,H,HD) as the qkv Linear emits it, HD in {16,32,64}, T <= 512; mask (B,T,ceil(T/32)) uint32 bitset, bit (j&31) of

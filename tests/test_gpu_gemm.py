@@ -468,3 +468,32 @@ def test_gemm_nt_ragged_edges(nb, R, N, K):
     out = flat[128:128 + nb * N * K].view(nb, N, K)
     gemm.wgrad_nt(dy, x, out)
     assert torch.equal(out, got) and bool((flat[:128] == 3.0).all()) and bool((flat[128 + nb * N * K:] == 3.0).all())
+
+
+@pytest.mark.parametrize("nb,R,N,K,splits", [(4, 8192, 1536, 384, 4), (4, 8192, 384, 384, 8), (12, 3328, 1152, 384, 2), (1, 8192, 96, 288, 4),
+                                              (2, 2048, 384, 1536, 2), (1, 4096, 576, 192, 8)])
+def test_gemm_nt_slab_sum_inside_the_launch(nb, R, N, K, splits):
+    """gm3d_gemm_nt_bf16_sum (the workgroup that finishes a tile's last slab adds the tile's slabs in slab order) == the slabs followed by
+    gm3d_sum_few_rows, bit for bit, on 20 consecutive launches (the arrival order of the workgroups varies, the result must not);
+    the tile counters are zero again afterwards; a pitched destination inside a larger buffer is respected.  (Off in the step:
+    measured slower, gemm.FUSE_SLAB_SUM.)"""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(R + N + K + splits)
+    dy = torch.randn(nb, R, N, device="cuda", generator=g).bfloat16()
+    x = torch.randn(nb, R, K, device="cuda", generator=g).bfloat16()
+    was = gemm.FUSE_SLAB_SUM
+    try:
+        gemm.FUSE_SLAB_SUM = False
+        want = gemm.wgrad_nt(dy, x, splits=splits)
+        gemm.FUSE_SLAB_SUM = True
+        for _ in range(20):
+            got = gemm.wgrad_nt(dy, x, splits=splits)
+            assert torch.equal(got, want)
+        buf = gemm._nt_counters[str(dy.device)][0]
+        assert int(buf.abs().max()) == 0
+        flat = torch.full((nb * N * K + 512,), 3.0, device="cuda")
+        out = flat[256:256 + nb * N * K].view(nb, N, K)
+        gemm.wgrad_nt(dy, x, out, splits=splits)
+        assert torch.equal(out, want) and bool((flat[:256] == 3.0).all()) and bool((flat[256 + nb * N * K:] == 3.0).all())
+    finally:
+        gemm.FUSE_SLAB_SUM = was
