@@ -132,7 +132,7 @@ class EmbedFn(torch.autograd.Function):
         if pool_fused:      # conv2 + bias + max-pool in one launch: f is written for conv3, (fg, arg1) come from the same tile
             f, fg, arg1 = gemm.linear_pool(a1, W2, _c32(b2), bias_after_pool=False, want_rows=True)
         else:
-            f = torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
+            f = gemm.mm(a1, W2, _c32(b2)) if adt == torch.bfloat16 else torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
             fg = torch.empty(BG, C2, dtype=adt, device=dev)
             arg1 = torch.empty(BG, C2, dtype=torch.uint8, device=dev)
             _launch("gm3d_group_max_fwd", {"G": BG, "K": K, "C": C2, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(f), None,
@@ -190,7 +190,7 @@ class EmbedFn(torch.autograd.Function):
             # conv4 + max-pool + bias: the (rows, 384) product never reaches HBM (the backward needs only arg2)
             _, tok, arg2 = gemm.linear_pool(a2, W4, b4f, bias_after_pool=True, want_rows=False)
         else:
-            z = a2 @ W4.t()
+            z = gemm.mm(a2, W4) if adt == torch.bfloat16 else a2 @ W4.t()     # groups of k != 32 points (Point-M2AE level 0: k = 16)
             tok = torch.empty(BGs, C4, dtype=adt, device=dev)
             arg2 = torch.empty(BGs, C4, dtype=torch.uint8, device=dev)
             _launch("gm3d_group_max_fwd", {"G": BGs, "K": K, "C": C4, "dtype": str(adt)}, lib.gm3d_group_max_fwd, _ptr(z),
