@@ -159,3 +159,38 @@ def test_collection_from_the_repo_root_needs_no_gpu():
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "tools/" not in r.stdout and "error" not in r.stdout.lower().split("\n")[-2]
+
+
+def test_gemm_table_names_a_hand_written_kernel_for_every_shape_of_the_path():
+    """gemm.choose (the per-shape kernel table read off profiles/r03_gemm_kbench.txt) never answers "lib": every plain product of the
+    bf16 step -- block stacks at the student's / teacher's row counts, mini-PointNet, heads -- has a hand-written kernel, and the answer
+    is one mm() knows how to dispatch."""
+    from gm3d_amd import gemm
+    shapes = [(M, N, K) for M in (3200, 3328, 4096, 8192) for (N, K) in ((1152, 384), (384, 384), (1536, 384), (384, 1536), (384, 1152))]
+    shapes += [(262144, 256, 128), (262144, 512, 256), (262144, 384, 512), (102400, 384, 512), (102400, 512, 384), (262144, 256, 512),
+               (262144, 128, 256), (8192, 512, 256), (8192, 256, 512), (8192, 384, 128), (8192, 128, 384), (8192, 1024, 384), (8192, 384, 1024)]
+    for M, N, K in shapes:
+        how = gemm.choose(M, N, K)
+        assert how != "lib" and (how == "own" or how.startswith("ring") or how.startswith("dma")), (M, N, K, how)
+        if how.startswith("dma"):
+            bm, bn = how[3:].split("x")
+            assert int(bm) in (64, 128) and N % int(bn) == 0, (M, N, K, how)
+
+
+def test_drop_path_scales_are_drawn_per_site_and_consumed_in_plan_order(M):
+    """prepare_drop_path draws the factors of several stacks in one go and drop_path_scales hands them out in that order; a request
+    that does not match the plan falls back to a fresh draw (host logic only: CPU tensors)."""
+    import torch
+    dev = torch.device("cpu")
+    torch.manual_seed(0)
+    plan = [[0.0, 0.0, 0.1, 0.1], [0.05, 0.05]]
+    M.prepare_drop_path(4, plan, True, dev)
+    a = M.drop_path_scales(4, plan[0], True, dev)
+    b = M.drop_path_scales(4, plan[1], True, dev)
+    assert a[0] is None and a[1] is None and a[2].shape == (4,) and b[0].shape == (4,)
+    for t, p in ((a[2], 0.1), (a[3], 0.1), (b[0], 0.05), (b[1], 0.05)):          # floor(keep + u) / keep is 0 or 1 / keep
+        keep = 1.0 - p
+        assert bool(((t == 0) | ((t - 1.0 / keep).abs() < 1e-6)).all())
+    c = M.drop_path_scales(4, [0.2], True, dev)                                   # no plan left: drawn on the spot
+    assert c[0].shape == (4,)
+    assert M.drop_path_scales(4, [0.2], False, dev) == [None]                      # eval mode: inactive
