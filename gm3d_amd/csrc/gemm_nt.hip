@@ -58,18 +58,13 @@ __device__ __forceinline__ nbf16x8 nt_frag(const unsigned char* img, int kk0, in
 
 // grid.x = batch * splits * tiles_n * tiles_k (rounded up to a multiple of 8, XCD-aware order).  Rows of split s:
 // [s * rows_split, (s + 1) * rows_split); rows_split % 32 == 0.
-__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
-                                                              float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
-                                                              long long sY, long long sX, long long sO, long long sOs, int splits,
-                                                              int tiles_n, int tiles_k, int total, int Nfull, int Kfull,
-                                                              int* __restrict__ counters, float* __restrict__ Ofin, long long sOfin,
-                                                              int ldofin) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+// one 128 x 128 output tile of one (batch, split): `logical` = this workgroup's tile number inside its problem (XCD-aware order already applied)
+__device__ __forceinline__ void nt_tile(unsigned char* nsm, const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X, float* __restrict__ O,
+                                        int rows_split, int ldy, int ldx, int ldo, long long sY, long long sX, long long sO, long long sOs,
+                                        int splits, int tiles_n, int tiles_k, int logical, int Nfull, int Kfull, int* __restrict__ counters,
+                                        float* __restrict__ Ofin, long long sOfin, int ldofin) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
-    const int per_xcd = gridDim.x >> 3;
-    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-    if (logical >= total) return;
     int t = logical;
     const int tk = t % tiles_k; t /= tiles_k;
     const int tn = t % tiles_n; t /= tiles_n;
@@ -185,6 +180,55 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __re
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X,
+                                                              float* __restrict__ O, int rows_split, int ldy, int ldx, int ldo,
+                                                              long long sY, long long sX, long long sO, long long sOs, int splits,
+                                                              int tiles_n, int tiles_k, int total, int Nfull, int Kfull,
+                                                              int* __restrict__ counters, float* __restrict__ Ofin, long long sOfin,
+                                                              int ldofin) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+    const int per_xcd = gridDim.x >> 3;
+    const int logical = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (logical >= total) return;
+    nt_tile(nsm, Y, X, O, rows_split, ldy, ldx, ldo, sY, sX, sO, sOs, splits, tiles_n, tiles_k, logical, Nfull, Kfull, counters, Ofin, sOfin,
+            ldofin);
+}
+
+// ---- several weight-gradient problems in ONE launch ------------------------------------------------------------------------------------
+// The twelve batched products of a step's three block stacks (4 weight kinds each) used to be twelve launches of 60-100 us, each with its
+// own ramp and its own partly filled last wave of tiles, on a stream where that time is ~90 % exposed.  Here they are one grid: problem j
+// owns workgroups [first_j, first_j + grid_j) (grid_j = its tile count rounded up to 8, so blockIdx & 7 -- the XCD -- and the order of
+// tiles inside a problem are exactly those of its own launch); workgroups are dealt in order, so the next problem's tiles fill the CUs
+// the previous one's tail leaves idle.  The descriptors travel by value in the kernel arguments (captured with the node in a hipGraph).
+struct NtProblem {
+    const bf16_t* Y;
+    const bf16_t* X;
+    float* O;
+    long long sY, sX, sO, sOs;
+    int rows_split, ldy, ldx, ldo, splits, tiles_n, tiles_k, total, N, K, first, grid;
+};
+constexpr int NT_MAXP = 16;
+struct NtMulti {
+    int count;
+    NtProblem p[NT_MAXP];
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_nt_multi_kernel(NtMulti m) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nsm[];
+    const int bid = blockIdx.x;
+    // the problem of this workgroup: a scan with compile-time indices (a run-time index into a by-value struct would go through scratch)
+    NtProblem q = m.p[0];
+#pragma unroll
+    for (int j = 1; j < NT_MAXP; ++j)
+        if (j < m.count && bid >= m.p[j].first) q = m.p[j];
+    const int local = bid - q.first;
+    const int per_xcd = q.grid >> 3;
+    const int logical = (local & 7) * per_xcd + (local >> 3);
+    if (logical >= q.total) return;
+    nt_tile(nsm, q.Y, q.X, q.O, q.rows_split, q.ldy, q.ldx, q.ldo, q.sY, q.sX, q.sO, q.sOs, q.splits, q.tiles_n, q.tiles_k, logical, q.N, q.K,
+            nullptr, nullptr, 0, 0);
 }
 
 // ---- 128 x 384 output tiles (the block stacks' weight gradients: every (N, K) there is a multiple of (128, 384)) ----------------------
@@ -414,6 +458,104 @@ extern "C" int gm3d_gemm_nt_bf16_sum(const void* dY, const void* X, float* part,
     if (!part || !out || !counters || splits < 2 || ldo < K || ldo % 4 || ((size_t)out & 15) || ((size_t)part & 15) || K % 4) return GM3D_EINVAL;
     return nt_launch(dY, X, part, batch, R, N, K, ldy, ldx, K, stride_y, stride_x, (long long)splits * N * K, splits, (long long)N * K, stream,
                      counters, out, stride_o, ldo);
+}
+
+namespace gm3d {
+// out[b] = sum over the row splits of part[b][s], for several problems in one launch (grid.y = problem, grid.z = batch): the slab sums of
+// gm3d_gemm_nt_bf16_multi, in slab order like gm3d_sum_few_rows.
+struct NtSumJob {
+    const float* src;
+    float* dst;
+    long long src_bstride, dst_bstride;      // in floats
+    int nrows, batch;
+    long long ncols4;
+};
+struct NtSumMulti {
+    int count;
+    NtSumJob j[NT_MAXP];
+};
+
+__global__ __launch_bounds__(256) void nt_sum_multi_kernel(NtSumMulti m) {
+    NtSumJob q = m.j[0];
+#pragma unroll
+    for (int j = 1; j < NT_MAXP; ++j)
+        if (j < m.count && (int)blockIdx.y == j) q = m.j[j];
+    if ((int)blockIdx.z >= q.batch) return;
+    const float4* p = reinterpret_cast<const float4*>(q.src + (size_t)blockIdx.z * q.src_bstride);
+    float4* o = reinterpret_cast<float4*>(q.dst + (size_t)blockIdx.z * q.dst_bstride);
+    for (size_t c = (size_t)blockIdx.x * 256 + threadIdx.x; c < (size_t)q.ncols4; c += (size_t)gridDim.x * 256) {
+        float4 a = p[c];
+#pragma unroll 8
+        for (int r = 1; r < q.nrows; ++r) {
+            const float4 b = p[(size_t)r * q.ncols4 + c];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        o[c] = a;
+    }
+}
+}  // namespace gm3d
+
+// `count` (<= 16) weight-gradient problems -- each what gm3d_gemm_nt_bf16 computes, 128 x 128 tiles -- in ONE launch, followed by ONE launch
+// that adds the row-split slabs of every problem with splits > 1 (part[j]: (batch, splits, N, K) f32 scratch; out[j]: (batch, N, K)
+// contiguous rows of K, batch stride stride_o[j]).  Problems with splits == 1 write out[j] directly.  Results are bit-identical to the
+// separate launches (same tiles, same slab order).
+extern "C" int gm3d_gemm_nt_bf16_multi(int count, const void* const* dY, const void* const* X, float* const* out, float* const* part,
+                                       const int* batch, const int* R, const int* N, const int* K, const int* ldy, const int* ldx,
+                                       const long long* stride_y, const long long* stride_x, const long long* stride_o, const int* splits,
+                                       gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (count < 1 || count > NT_MAXP || !dY || !X || !out || !part || !batch || !R || !N || !K || !ldy || !ldx || !stride_y || !stride_x ||
+        !stride_o || !splits)
+        return GM3D_EINVAL;
+    NtMulti m;
+    NtSumMulti sm;
+    m.count = count;
+    sm.count = 0;
+    long long first = 0;
+    int max_batch = 1;
+    long long max_cols4 = 0;
+    for (int j = 0; j < count; ++j) {
+        if (!dY[j] || !X[j] || !out[j] || batch[j] < 1 || R[j] < 1 || N[j] < 1 || K[j] < 1 || splits[j] < 1) return GM3D_EINVAL;
+        if (N[j] % 8 || K[j] % 8 || ldy[j] % 8 || ldx[j] % 8 || ldy[j] < N[j] || ldx[j] < K[j] || R[j] % (NT_BR * splits[j]) || K[j] % 4)
+            return GM3D_EUNSUPPORTED;
+        if ((((size_t)dY[j] | (size_t)X[j]) & 15) || ((size_t)out[j] & 15)) return GM3D_EUNSUPPORTED;
+        if (splits[j] > 1 && (!part[j] || ((size_t)part[j] & 15) || splits[j] > 64)) return GM3D_EINVAL;
+        if (stride_o[j] < (long long)N[j] * K[j]) return GM3D_EINVAL;
+        NtProblem& q = m.p[j];
+        const int tn_ = (N[j] + 127) / 128, tk_ = (K[j] + 127) / 128;
+        const long long total = (long long)batch[j] * splits[j] * tn_ * tk_;
+        if (first + total > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+        q.Y = (const bf16_t*)dY[j]; q.X = (const bf16_t*)X[j];
+        q.sY = stride_y[j]; q.sX = stride_x[j];
+        q.rows_split = R[j] / splits[j]; q.ldy = ldy[j]; q.ldx = ldx[j]; q.ldo = K[j];
+        q.splits = splits[j]; q.tiles_n = tn_; q.tiles_k = tk_; q.total = (int)total; q.N = N[j]; q.K = K[j];
+        q.first = (int)first; q.grid = (int)((total + 7) / 8 * 8);
+        if (splits[j] > 1) {
+            q.O = part[j]; q.sO = (long long)splits[j] * N[j] * K[j]; q.sOs = (long long)N[j] * K[j];
+            NtSumJob& sj = sm.j[sm.count++];
+            sj.src = part[j]; sj.dst = out[j]; sj.src_bstride = q.sO; sj.dst_bstride = stride_o[j];
+            sj.nrows = splits[j]; sj.batch = batch[j]; sj.ncols4 = (long long)N[j] * K[j] / 4;
+            if (batch[j] > max_batch) max_batch = batch[j];
+            if (sj.ncols4 > max_cols4) max_cols4 = sj.ncols4;
+        } else {
+            q.O = out[j]; q.sO = stride_o[j]; q.sOs = 0;
+        }
+        first += q.grid;
+    }
+    for (int j = count; j < NT_MAXP; ++j) m.p[j] = m.p[0];
+    for (int j = sm.count; j < NT_MAXP; ++j) sm.j[j] = sm.j[0];
+    const size_t lds = (size_t)NT_NBUF * NT_STAGE;
+    static LdsAttr attr;
+    if (!attr.ensure((const void*)gemm_nt_multi_kernel, lds)) return GM3D_ELAUNCH;
+    hipLaunchKernelGGL(gemm_nt_multi_kernel, dim3((unsigned)first), dim3(256), lds, (hipStream_t)stream, m);
+    GM3D_CHECK_LAUNCH();
+    if (sm.count > 0) {
+        if (max_batch > 65535) return GM3D_EUNSUPPORTED;
+        const int gx = (int)((max_cols4 + 255) / 256 < 256 ? (max_cols4 + 255) / 256 : 256);
+        hipLaunchKernelGGL(nt_sum_multi_kernel, dim3(gx, sm.count, max_batch), dim3(256), 0, (hipStream_t)stream, sm);
+        GM3D_CHECK_LAUNCH();
+    }
+    return GM3D_OK;
 }
 
 extern "C" int gm3d_gemm_nt_tiles(int N, int K) { return N < 1 || K < 1 ? 0 : ((N + 127) / 128) * ((K + 127) / 128); }

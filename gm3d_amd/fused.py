@@ -272,13 +272,25 @@ WGRAD_MIN_BLOCKS = 5      # stacks with fewer blocks (the 4-block decoders) DEFE
 _ASYNC_WGRAD = {"stream": None, "used": False, "min_blocks": 5, "deferred": []}
 
 
-def _run_deferred(reg):
+def _wgrad_many(reqs):
+    """[(dy, x, out slot | None), ...] -> [dW, ...]: one launch for all of them where the NT kernel takes every request
+    (gemm.wgrad_nt_multi), else one batched GEMM per request."""
+    if gemm.MULTI_WGRAD and 1 < len(reqs) <= 16 and all(gemm.wgrad_multi_ok(dy, x, out) for dy, x, out in reqs):
+        return gemm.wgrad_nt_multi(reqs)
+    return [_wgrad_batched(dy, x, out) for dy, x, out in reqs]
+
+
+def _run_deferred(reg, own=()):
+    """the deferred stacks' weight-gradient requests, plus `own` (the calling stack's), on the current stream -> the results of `own`"""
     jobs, reg["deferred"] = reg["deferred"], []
     cur = torch.cuda.current_stream()
-    for tensors, job in jobs:
+    reqs = []
+    for tensors, rq in jobs:
         for t in tensors:
             t.record_stream(cur)
-        job()
+        reqs += rq
+    res = _wgrad_many(reqs + list(own)) if (reqs or own) else []
+    return res[len(reqs):]
 
 _wgrad_streams = {}
 ASYNC_WGRAD = True       # (tests flip it)
@@ -559,9 +571,9 @@ class TransformerStackFn(torch.autograd.Function):
         ws = reg["stream"] if fresh else None
         slots = [slot(k) for k in (9, 7, 3, 2)] if fresh else [None] * 4
         jobs = [(DO, GG), (DF, H2), (DP, A), (DQ, H1)]
+        own = [(dy_, x_, sl) for (dy_, x_), sl in zip(jobs, slots)]
         if ws is not None and nblk < reg["min_blocks"] and all(sl is not None for sl in slots):
-            reg["deferred"].append(((DO, GG, DF, H2, DP, A, DQ, H1),
-                                    lambda: [_wgrad_batched(dy_, x_, sl) for (dy_, x_), sl in zip(jobs, slots)]))
+            reg["deferred"].append(((DO, GG, DF, H2, DP, A, DQ, H1), own))
             gw2, gw1, gwp, gwq = slots
         else:
             if ws is not None and nblk >= reg["min_blocks"]:
@@ -572,9 +584,8 @@ class TransformerStackFn(torch.autograd.Function):
             else:
                 ws = None
             with (torch.cuda.stream(ws) if ws is not None else contextlib.nullcontext()):
-                if ws is not None:
-                    _run_deferred(reg)
-                gw2, gw1, gwp, gwq = [_wgrad_batched(dy_, x_, sl) for (dy_, x_), sl in zip(jobs, slots)]
+                # the deferred decoders' requests and this stack's own: ONE launch (+ one slab sum) where the kernel takes them all
+                gw2, gw1, gwp, gwq = _run_deferred(reg, own) if ws is not None else _wgrad_many(own)
         for i in range(nblk):
             grads[i * PER_BLOCK + 9], grads[i * PER_BLOCK + 7] = gw2[i], gw1[i]
             grads[i * PER_BLOCK + 3], grads[i * PER_BLOCK + 2] = gwp[i], gwq[i]

@@ -415,6 +415,45 @@ def wgrad_nt(dy, x, out=None, splits=None):
     return out
 
 
+MULTI_WGRAD = False       # the weight gradients of several stacks as ONE launch (+ one slab-sum launch): gm3d_gemm_nt_bf16_multi -- bit-identical,
+#                           22 launches fewer per step, and no faster (same-box A/B 7.64 vs 7.60 ms): that region is throughput-bound, not launch-bound
+
+
+def wgrad_multi_ok(dy, x, out):
+    """a request wgrad_nt_multi takes: what wgrad_nt takes, with a destination of dense (N,K) matrices at a constant batch stride"""
+    nb, R, N = dy.shape
+    K = x.shape[2]
+    return (wgrad_supported(dy, x) and K % 4 == 0
+            and (out is None or (out.dtype == torch.float32 and out.shape == (nb, N, K) and out.stride(2) == 1 and out.stride(1) == K
+                                 and (nb == 1 or out.stride(0) >= N * K) and out.data_ptr() % 16 == 0)))
+
+
+def wgrad_nt_multi(reqs):
+    """[(dy (nb,R,N), x (nb,R,K), out (nb,N,K) f32 | None), ...] (at most 16) -> [out, ...]: every product dy[b]^T @ x[b] of every request
+    in ONE launch of the 128 x 128-tile weight-gradient kernel, then ONE launch that adds the row-split slabs (csrc/gemm_nt.hip
+    gm3d_gemm_nt_bf16_multi).  Bit-identical to wgrad_nt per request."""
+    import ctypes
+    n = len(reqs)
+    VP, I, LL = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
+    outs, parts, spl = [], [], []
+    for dy, x, out in reqs:
+        nb, R, N = dy.shape
+        K = x.shape[2]
+        if out is None:
+            out = torch.empty(nb, N, K, dtype=torch.float32, device=dy.device)
+        s_ = lib.gm3d_gemm_nt_splits(nb, R, N, K)
+        outs.append(out)
+        spl.append(s_)
+        parts.append(torch.empty(nb, s_, N, K, dtype=torch.float32, device=dy.device) if s_ > 1 else None)
+    _launch("gm3d_gemm_nt_bf16_multi", {"count": n}, lib.gm3d_gemm_nt_bf16_multi, n,
+            VP(*[_ptr(r[0]) for r in reqs]), VP(*[_ptr(r[1]) for r in reqs]), VP(*[_ptr(o) for o in outs]),
+            VP(*[(_ptr(p) if p is not None else None) for p in parts]), I(*[r[0].shape[0] for r in reqs]), I(*[r[0].shape[1] for r in reqs]),
+            I(*[r[0].shape[2] for r in reqs]), I(*[r[1].shape[2] for r in reqs]), I(*[r[0].stride(1) for r in reqs]),
+            I(*[r[1].stride(1) for r in reqs]), LL(*[r[0].stride(0) for r in reqs]), LL(*[r[1].stride(0) for r in reqs]),
+            LL(*[o.stride(0) for o in outs]), I(*spl), _stream())
+    return outs
+
+
 def tile_rows(M):
     return lib.gm3d_gemm_tile_rows(int(M))
 

@@ -513,6 +513,14 @@ int gm3d_gemm_nt_set_big_tiles(int on);
 int gm3d_gemm_nt_bf16_sum(const void *dY, const void *X, float *part, float *out, int *counters, int batch, int R, int N, int K, int ldy,
                           int ldx, int ldo, long long stride_y, long long stride_x, long long stride_o, int splits, gm3d_stream_t stream);
 int gm3d_gemm_nt_tiles(int N, int K);
+/* `count` (<= 16) problems of gm3d_gemm_nt_bf16 (128 x 128 tiles) as ONE launch + ONE slab-sum launch: the twelve batched weight
+ * gradients of a step's three block stacks (timm Block qkv / proj / fc1 / fc2, P/models/Point_MAE.py:82-125) without twelve ramps and
+ * partly filled last waves.  Per problem j: dY[j] (batch, R, N) bf16 rows of pitch ldy[j], X[j] (batch, R, K), out[j] (batch, N, K) f32
+ * with batch stride stride_o[j], part[j] (batch, splits, N, K) f32 scratch when splits[j] > 1 (else ignored).  Bit-identical to the
+ * separate launches.  The descriptors are passed by value (a captured launch keeps them). */
+int gm3d_gemm_nt_bf16_multi(int count, const void *const *dY, const void *const *X, float *const *out, float *const *part, const int *batch,
+                            const int *R, const int *N, const int *K, const int *ldy, const int *ldx, const long long *stride_y,
+                            const long long *stride_x, const long long *stride_o, const int *splits, gm3d_stream_t stream);
 /* Masked multi-head attention of the hierarchical (Point-M2AE) encoder blocks -- SURVEY.md 8f.4; the reference ships only the
  * hyper-parameters (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: dims 96/192/384, 6 heads, local_radius 0.32/0.64/1.28).
  * qkv (B,T,3,H,HD) as the qkv Linear emits it, HD in {16,32,64}, T <= 512; mask (B,T,ceil(T/32)) uint32 bitset, bit (j&31) of

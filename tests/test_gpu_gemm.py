@@ -497,3 +497,32 @@ def test_gemm_nt_slab_sum_inside_the_launch(nb, R, N, K, splits):
         assert torch.equal(out, want) and bool((flat[:256] == 3.0).all()) and bool((flat[256 + nb * N * K:] == 3.0).all())
     finally:
         gemm.FUSE_SLAB_SUM = was
+
+
+def test_gemm_nt_multi_problem_launch_equals_separate_launches():
+    """gm3d_gemm_nt_bf16_multi: the twelve weight-gradient products of three block stacks (decoders: 4 blocks x 8192 rows, encoder: 12 x
+    3328) as ONE launch + ONE slab-sum launch == wgrad_nt per request, bit for bit; destinations at a batch stride inside a larger flat
+    buffer (the optimizer's gradient slots) stay clean around the slots."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(4)
+    reqs, flats = [], []
+    for nb, R in ((4, 8192), (4, 8192), (12, 3328)):
+        for N, K in ((384, 1536), (1536, 384), (384, 384), (1152, 384)):
+            dy = torch.randn(nb, R, N, device="cuda", generator=g).bfloat16()
+            x = torch.randn(nb, R, K, device="cuda", generator=g).bfloat16()
+            stride = N * K + 256                                     # slots of a flat buffer with other parameters in between
+            flat = torch.full((nb * stride + 64,), 3.0, device="cuda")
+            out = torch.as_strided(flat, (nb, N, K), (stride, K, 1), 64)
+            reqs.append((dy, x, out))
+            flats.append((flat, stride, N * K, nb))
+    assert all(gemm.wgrad_multi_ok(*r) for r in reqs)
+    want = [gemm.wgrad_nt(dy, x) for dy, x, _ in reqs]
+    got = gemm.wgrad_nt_multi(reqs)
+    for w, o, (flat, stride, nk, nb) in zip(want, got, flats):
+        assert torch.equal(o, w)
+        assert bool((flat[:64] == 3.0).all())
+        for b in range(nb):
+            assert bool((flat[64 + b * stride + nk:64 + (b + 1) * stride] == 3.0).all())
+    got2 = gemm.wgrad_nt_multi([(dy, x, None) for dy, x, _ in reqs[:5]])
+    for w, o in zip(want[:5], got2):
+        assert torch.equal(o, w)
