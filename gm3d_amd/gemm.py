@@ -415,8 +415,11 @@ def wgrad_nt(dy, x, out=None, splits=None):
     return out
 
 
-MULTI_WGRAD = False       # the weight gradients of several stacks as ONE launch (+ one slab-sum launch): gm3d_gemm_nt_bf16_multi -- bit-identical,
-#                           22 launches fewer per step, and no faster (same-box A/B 7.64 vs 7.60 ms): that region is throughput-bound, not launch-bound
+MULTI_SPLITS_MAX = 2      # with MULTI_WGRAD: cap on the row splits of the 8192-row problems (1 for <= 4096 rows) when the whole launch has >= 768 tiles:
+#                           the launch as a whole fills the chip, so a problem needs splits only against a long tail (0 = keep each problem's own)
+MULTI_WGRAD = True        # the weight gradients of several stacks as ONE launch (+ one slab-sum launch): gm3d_gemm_nt_bf16_multi.  With each
+#                           problem's own splits: 22 launches fewer and no faster (7.64 vs 7.60 ms same-box); with the splits capped as above (fewer
+#                           slabs to write and add): 7.56 vs 7.65 ms, +1.1 %
 
 
 def wgrad_multi_ok(dy, x, out):
@@ -428,20 +431,30 @@ def wgrad_multi_ok(dy, x, out):
                                  and (nb == 1 or out.stride(0) >= N * K) and out.data_ptr() % 16 == 0)))
 
 
-def wgrad_nt_multi(reqs):
+def wgrad_nt_multi(reqs, splits=None, want_splits=False):
     """[(dy (nb,R,N), x (nb,R,K), out (nb,N,K) f32 | None), ...] (at most 16) -> [out, ...]: every product dy[b]^T @ x[b] of every request
     in ONE launch of the 128 x 128-tile weight-gradient kernel, then ONE launch that adds the row-split slabs (csrc/gemm_nt.hip
-    gm3d_gemm_nt_bf16_multi).  Bit-identical to wgrad_nt per request."""
+    gm3d_gemm_nt_bf16_multi).  Bit-identical to wgrad_nt per request with the same row splits (splits=: one per request; default: each
+    request's own choice, capped by MULTI_SPLITS_MAX when the launch is large)."""
     import ctypes
     n = len(reqs)
     VP, I, LL = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
     outs, parts, spl = [], [], []
+    tiles_all = sum(r[0].shape[0] * ((r[0].shape[2] + 127) // 128) * ((r[1].shape[2] + 127) // 128) for r in reqs)
     for dy, x, out in reqs:
         nb, R, N = dy.shape
         K = x.shape[2]
         if out is None:
             out = torch.empty(nb, N, K, dtype=torch.float32, device=dy.device)
         s_ = lib.gm3d_gemm_nt_splits(nb, R, N, K)
+        if splits is not None:
+            s_ = splits[len(spl)]
+        elif MULTI_SPLITS_MAX and tiles_all >= 768:
+            # the launch as a whole fills the chip many times over: a problem needs row splits only to keep its tiles from running
+            # much longer than the others' (tail), not to fill CUs -- fewer slabs to write and add
+            s_ = min(s_, MULTI_SPLITS_MAX if R > 4096 else 1)
+            while s_ > 1 and R % (32 * s_):
+                s_ -= 1
         outs.append(out)
         spl.append(s_)
         parts.append(torch.empty(nb, s_, N, K, dtype=torch.float32, device=dy.device) if s_ > 1 else None)
@@ -451,7 +464,7 @@ def wgrad_nt_multi(reqs):
             I(*[r[0].shape[2] for r in reqs]), I(*[r[1].shape[2] for r in reqs]), I(*[r[0].stride(1) for r in reqs]),
             I(*[r[1].stride(1) for r in reqs]), LL(*[r[0].stride(0) for r in reqs]), LL(*[r[1].stride(0) for r in reqs]),
             LL(*[o.stride(0) for o in outs]), I(*spl), _stream())
-    return outs
+    return (outs, spl) if want_splits else outs
 
 
 def tile_rows(M):

@@ -516,13 +516,15 @@ def test_gemm_nt_multi_problem_launch_equals_separate_launches():
             reqs.append((dy, x, out))
             flats.append((flat, stride, N * K, nb))
     assert all(gemm.wgrad_multi_ok(*r) for r in reqs)
-    want = [gemm.wgrad_nt(dy, x) for dy, x, _ in reqs]
-    got = gemm.wgrad_nt_multi(reqs)
+    got, used = gemm.wgrad_nt_multi(reqs, want_splits=True)             # the launch's own (capped) row splits
+    assert max(used) <= max(gemm.MULTI_SPLITS_MAX, 1) or not gemm.MULTI_SPLITS_MAX
+    want = [gemm.wgrad_nt(dy, x, splits=sp) for (dy, x, _), sp in zip(reqs, used)]
     for w, o, (flat, stride, nk, nb) in zip(want, got, flats):
         assert torch.equal(o, w)
         assert bool((flat[:64] == 3.0).all())
         for b in range(nb):
             assert bool((flat[64 + b * stride + nk:64 + (b + 1) * stride] == 3.0).all())
-    got2 = gemm.wgrad_nt_multi([(dy, x, None) for dy, x, _ in reqs[:5]])
-    for w, o in zip(want[:5], got2):
-        assert torch.equal(o, w)
+    own = [gemm.lib.gm3d_gemm_nt_splits(dy.shape[0], dy.shape[1], dy.shape[2], x.shape[2]) for dy, x, _ in reqs[:5]]
+    got2 = gemm.wgrad_nt_multi([(dy, x, None) for dy, x, _ in reqs[:5]], splits=own)      # given splits, fresh destinations
+    for (dy, x, _), o in zip(reqs[:5], got2):
+        assert torch.equal(o, gemm.wgrad_nt(dy, x))
