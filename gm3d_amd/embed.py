@@ -228,7 +228,18 @@ class EmbedFn(torch.autograd.Function):
                 _ptr(arg2), _ptr(dz), BGs, K, C4, dt_id, _stream())
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         da2 = gemm.mm_nn(dz, W4)
-        dW4 = splitk_wgrad(dz, a2)
+        # the four weight-gradient products of this node: ONE launch at the end (gemm.wgrad_nt_multi: together they fill the chip with
+        # row splits in proportion to their rows) instead of four launches that each cut themselves into 64 slabs
+        later = []
+        multi = gemm.MULTI_WGRAD and adt == torch.bfloat16 and gemm.ENABLED
+
+        def wgrad(dy_, x_):
+            if multi and dy_.is_contiguous() and x_.is_contiguous() and gemm.wgrad_multi_ok(dy_.unsqueeze(0), x_.unsqueeze(0), None):
+                out = torch.empty(1, dy_.shape[1], x_.shape[1], dtype=torch.float32, device=dev)
+                later.append((dy_.unsqueeze(0), x_.unsqueeze(0), out))
+                return out[0]
+            return splitk_wgrad(dy_, x_)
+        dW4 = wgrad(dz, a2)
         # BN2 + ReLU: the sums run over the rows that carry a gradient, dy is written for every row
         nrows = lib.gm3d_embed_partial_rows(1, BGs, C3)
         part = torch.empty(nrows, 2 * C3, dtype=torch.float32, device=dev)
@@ -250,12 +261,11 @@ class EmbedFn(torch.autograd.Function):
         if bf16:            # one transposing launch for both halves: rows [0, C2) of W3^T multiply the per-group term, the rest the rows
             W3T = gemm.transposed(W3)
         df = gemm.mm(dy, W3T[C2:]) if bf16 else dy @ W3l
-        dW3l = splitk_wgrad(dy, f)
+        dW3l = wgrad(dy, f)
         db3 = colsum(dt, torch.float32)
         dta = dt.to(adt)
-        dW3g = splitk_wgrad(dta, fg)
+        dW3g = wgrad(dta, fg)
         dfg = gemm.mm(dta, W3T[:C2]) if bf16 else dta @ W3g
-        dW3 = torch.cat([dW3g, dW3l], dim=1).reshape(w3.shape)
         # max-pool branch joins df; bias grad of conv2
         nrows = lib.gm3d_embed_partial_rows(1, BG, C2)
         part = torch.empty(nrows, C2, dtype=torch.float32, device=dev)
@@ -265,7 +275,7 @@ class EmbedFn(torch.autograd.Function):
         # conv2
         W2 = weight_cache.get(w2, adt).reshape(C2, C1)
         da1 = gemm.mm_nn(df, W2)
-        dW2 = splitk_wgrad(df, a1).reshape(w2.shape)
+        dW2 = wgrad(df, a1).reshape(w2.shape)
         # layer 1: BN1 + conv(K=3), reductions only
         W1 = _c32(w1.reshape(C1, 3))
         nrows = lib.gm3d_embed_partial_rows(3, R, C1)
@@ -284,6 +294,11 @@ class EmbedFn(torch.autograd.Function):
         _launch("gm3d_pn1_bwd_finalize", {"C": C1}, lib.gm3d_pn1_bwd_finalize, _ptr(q), _ptr(mcov), _ptr(W1), _ptr(g1f),
                 _ptr(rstd1), _ptr(dW1), _ptr(dg1), _ptr(dbe1), C1, _stream())
         db1 = torch.zeros_like(b1)                                       # bias in front of BatchNorm: exactly zero
+        if len(later) > 1:
+            gemm.wgrad_nt_multi(later)
+        elif later:
+            gemm.wgrad_nt(later[0][0], later[0][1], later[0][2])
+        dW3 = torch.cat([dW3g, dW3l], dim=1).reshape(w3.shape)
         return (None, None, dW1.reshape(w1.shape), db1, dg1, dbe1, dW2, db2, dW3, db3, dg2, dbe2,
                 dW4.reshape(w4.shape), db4, None, None, None, None, None, None)
 

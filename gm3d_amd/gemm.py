@@ -440,7 +440,9 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
     n = len(reqs)
     VP, I, LL = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n
     outs, parts, spl = [], [], []
-    tiles_all = sum(r[0].shape[0] * ((r[0].shape[2] + 127) // 128) * ((r[1].shape[2] + 127) // 128) for r in reqs)
+    tiles = [r[0].shape[0] * ((r[0].shape[2] + 127) // 128) * ((r[1].shape[2] + 127) // 128) for r in reqs]
+    tiles_all = sum(tiles)
+    rows_target = max(512, sum(t_ * r[0].shape[1] for t_, r in zip(tiles, reqs)) // 512)
     for dy, x, out in reqs:
         nb, R, N = dy.shape
         K = x.shape[2]
@@ -449,6 +451,13 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
         s_ = lib.gm3d_gemm_nt_splits(nb, R, N, K)
         if splits is not None:
             s_ = splits[len(spl)]
+        elif MULTI_SPLITS_MAX and tiles_all < 768:
+            # few tiles in all (the mini-PointNet's products: 2-12 tiles each over 8192 .. 262,144 rows): splits per problem in
+            # proportion to its rows, so that the launch has ~512 workgroups of about equal length (each problem on its own would cut
+            # itself into 64 slabs to fill the chip alone)
+            s_ = 1
+            while 2 * s_ <= min(64, R // rows_target) and R % (64 * s_) == 0:
+                s_ *= 2
         elif MULTI_SPLITS_MAX and tiles_all >= 768:
             # the launch as a whole fills the chip many times over: a problem needs row splits only to keep its tiles from running
             # much longer than the others' (tail), not to fill CUs -- fewer slabs to write and add
