@@ -95,6 +95,7 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_dma_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_gelu": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_transpose_bf16_batched": [_vp, _vp, _i, _i, _i, ctypes.c_longlong, _vp],
+    "gm3d_transpose_bf16_multi": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gm3d_token_assemble_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],
     "gm3d_token_assemble_bwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp],
     "gm3d_sum_few_rows": [_vp, _i, _i, ctypes.c_longlong, _vp, _vp],

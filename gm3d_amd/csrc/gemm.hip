@@ -322,6 +322,54 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
     }
 }
 
+// several batched transposes (the four transposed weight shadows a block stack's backward reads) in ONE launch: problem j owns blocks
+// [first_j, first_j + (cols_j / 64) (rows_j / 64) batch_j); descriptors by value in the kernel arguments
+struct TrProblem {
+    const bf16_t* src;
+    bf16_t* dst;
+    long long src_bstride;
+    int rows, cols, first;
+};
+constexpr int TR_MAXP = 8;
+struct TrMulti {
+    int count;
+    TrProblem p[TR_MAXP];
+};
+
+__global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TrMulti m) {
+    __shared__ bf16_t tile[64][66];
+    TrProblem q = m.p[0];
+#pragma unroll
+    for (int j = 1; j < TR_MAXP; ++j)
+        if (j < m.count && (int)blockIdx.x >= m.p[j].first) q = m.p[j];
+    int local = (int)blockIdx.x - q.first;
+    const int nx = q.cols / 64, ny = q.rows / 64;
+    const int bx = local % nx; local /= nx;
+    const int by = local % ny;
+    const int bz = local / ny;
+    const bf16_t* s = q.src + (size_t)bz * q.src_bstride;
+    bf16_t* d = q.dst + (size_t)bz * q.rows * q.cols;
+    const int r0 = by * 64, c0 = bx * 64;
+    const int tr = threadIdx.x >> 3, tc = (threadIdx.x & 7) * 8;
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int rr = tr + 32 * p;
+        float v[8];
+        V8<bf16_t>::load(s + (size_t)(r0 + rr) * q.cols + c0 + tc, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tile[rr][tc + e] = (bf16_t)v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int cc = tr + 32 * p;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)tile[tc + e][cc];
+        V8<bf16_t>::store(d + (size_t)(c0 + cc) * q.rows + r0 + tc, v);
+    }
+}
+
 }  // namespace gm3d
 
 // 64-row tiles for the short token streams (3200 rows x N/128 column tiles is 75-300 workgroups for 512 slots), 128 otherwise
@@ -435,6 +483,29 @@ extern "C" int gm3d_gemm_tn_bf16_lna(const void* U16, const float* stats, const 
 }
 
 extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gemm_tile_height(M) - 1) / gemm_tile_height(M); }
+
+// `count` (<= 8) batched transposes dst[j][b][c][r] = src[j][b][r][c] in ONE launch (rows, cols multiples of 64; src batches at
+// src_batch_stride[j] elements, dst dense).
+extern "C" int gm3d_transpose_bf16_multi(int count, const void* const* src, void* const* dst, const int* batch, const int* rows, const int* cols,
+                                         const long long* src_batch_stride, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (count < 1 || count > TR_MAXP || !src || !dst || !batch || !rows || !cols || !src_batch_stride) return GM3D_EINVAL;
+    TrMulti m;
+    m.count = count;
+    long long first = 0;
+    for (int j = 0; j < count; ++j) {
+        if (!src[j] || !dst[j] || batch[j] < 1 || rows[j] < 1 || cols[j] < 1 || src_batch_stride[j] < (long long)rows[j] * cols[j]) return GM3D_EINVAL;
+        if (rows[j] % 64 || cols[j] % 64) return GM3D_EUNSUPPORTED;
+        m.p[j].src = (const bf16_t*)src[j]; m.p[j].dst = (bf16_t*)dst[j]; m.p[j].src_bstride = src_batch_stride[j];
+        m.p[j].rows = rows[j]; m.p[j].cols = cols[j]; m.p[j].first = (int)first;
+        first += (long long)(cols[j] / 64) * (rows[j] / 64) * batch[j];
+        if (first > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
+    }
+    for (int j = count; j < TR_MAXP; ++j) m.p[j] = m.p[0];
+    hipLaunchKernelGGL(transpose_bf16_multi_kernel, dim3((unsigned)first), dim3(256), 0, (hipStream_t)stream, m);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
 
 extern "C" int gm3d_transpose_bf16_batched(const void* src, void* dst, int batch, int rows, int cols, long long src_batch_stride,
                                            gm3d_stream_t stream) {

@@ -493,12 +493,10 @@ class TransformerStackFn(torch.autograd.Function):
         w2s = [weight_cache.get(params[i * PER_BLOCK + 9], adt) for i in range(nblk)]
         fuse_mlp_bwd = gemm.ENABLED and gemm.FUSE_GELU_BWD and adt == torch.bfloat16 and dh.is_cuda
         if fuse_mlp_bwd:
-            W2T = gemm.stacked_transpose(w2s)                                                                   # (nblk, C, 4C)^T -> (nblk, 4C, C)
-            WPT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 3], adt) for i in range(nblk)])  # (nblk, C, C)
-            # fc1 / qkv input gradients as TN products on the LDS-DMA ring kernel (N = 384 columns, K = 1536 / 1152: its regime;
-            # 9.3-16.8 us against 11.6-21 us for the library's NN form in the step): two more transposed shadows per stack
-            W1T = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 7], adt) for i in range(nblk)])  # (nblk, C, 4C)
-            WQT = gemm.stacked_transpose([weight_cache.get(params[i * PER_BLOCK + 2], adt) for i in range(nblk)])  # (nblk, C, 3C)
+            # fc2^T (nblk, 4C, C), proj^T (nblk, C, C) and -- fc1 / qkv input gradients as TN products on the LDS-DMA ring kernel (N = 384
+            # columns, K = 1536 / 1152: its regime) -- fc1^T (nblk, C, 4C), qkv^T (nblk, C, 3C): ONE transposing launch for the four
+            W2T, WPT, W1T, WQT = gemm.stacked_transposes(
+                [w2s] + [[weight_cache.get(params[i * PER_BLOCK + k], adt) for i in range(nblk)] for k in (3, 7, 2)])
         dma_bwd = fuse_mlp_bwd and gemm.dma_supported(dh.reshape(R, C), W2T[0])
         bm_bwd = gemm.dma_bm(R)
         PGL = torch.empty(nblk, ((R + bm_bwd - 1) // bm_bwd if dma_bwd else gemm.tile_rows(R)) if fuse_mlp_bwd

@@ -500,6 +500,35 @@ def linear_gelu_bwd_dma(d_o, w2t, f, bias, df, colpart, bm=64):
     return df
 
 
+MULTI_TRANSPOSE = True    # the four transposed weight shadows of a stack's backward in ONE launch (gm3d_transpose_bf16_multi)
+
+
+def stacked_transposes(groups):
+    """[ws_0, ws_1, ...] (each a list of same-shaped (N,K) bf16 weights at a constant stride in one buffer) -> [stacked_transpose(ws_i)]:
+    ONE launch for all groups when every group has the regular layout, else one per group."""
+    import ctypes
+    ok = MULTI_TRANSPOSE and 1 < len(groups) <= 8
+    metas = []
+    for ws in groups:
+        w0 = ws[0]
+        n = len(ws)
+        step = (ws[1].data_ptr() - w0.data_ptr()) if n > 1 else w0.numel() * w0.element_size()
+        regular = (w0.dtype == torch.bfloat16 and w0.is_cuda and w0.dim() == 2 and w0.shape[0] % 64 == 0 and w0.shape[1] % 64 == 0
+                   and step > 0 and step % w0.element_size() == 0 and step // w0.element_size() >= w0.numel()
+                   and all(w.shape == w0.shape and w.is_contiguous() and w.data_ptr() - w0.data_ptr() == i * step for i, w in enumerate(ws)))
+        ok = ok and regular
+        metas.append((w0, n, step // w0.element_size()))
+    if not ok:
+        return [stacked_transpose(ws) for ws in groups]
+    outs = [torch.empty(n, w0.shape[1], w0.shape[0], dtype=w0.dtype, device=w0.device) for w0, n, _ in metas]
+    c = len(groups)
+    VP, I, LL = ctypes.c_void_p * c, ctypes.c_int * c, ctypes.c_longlong * c
+    _launch("gm3d_transpose_bf16_multi", {"count": c}, lib.gm3d_transpose_bf16_multi, c, VP(*[_ptr(m_[0]) for m_ in metas]),
+            VP(*[_ptr(o) for o in outs]), I(*[m_[1] for m_ in metas]), I(*[m_[0].shape[0] for m_ in metas]),
+            I(*[m_[0].shape[1] for m_ in metas]), LL(*[m_[2] for m_ in metas]), _stream())
+    return outs
+
+
 def stacked_transpose(ws):
     """[w_0 .. w_{n-1}] (each (N,K) bf16) -> (n, K, N) contiguous = the transposes, in ONE copy launch when the tensors sit at a
     constant stride in one buffer (the flat optimizer's bf16 shadow), two otherwise."""

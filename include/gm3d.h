@@ -479,6 +479,9 @@ int gm3d_gemm_tn_bf16_dma_gelu_bwd(const void *dO, const void *Wt, const void *F
  * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 64. */
 int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows, int cols, long long src_batch_stride,
                                 gm3d_stream_t stream);
+/* `count` (<= 8) of those in ONE launch (the four transposed weight shadows a block stack's backward reads). */
+int gm3d_transpose_bf16_multi(int count, const void *const *src, void *const *dst, const int *batch, const int *rows, const int *cols,
+                              const long long *src_batch_stride, gm3d_stream_t stream);
 /* Token / positional-embedding assembly around the mask (models_mae_learn_loss.py:298-300,649-658) in one pass each way.
  * order (B,L) int64 = [visible ids | masked ids], a permutation of 0..L-1 per sample (gm3d_mask_select writes exactly this when its
  * two id outputs are the halves of one (B,L) buffer).  fwd: x_vis, pos_vis (B,V,C) and pos_full (B,L,C) gathered from tokens / pos

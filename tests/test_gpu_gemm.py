@@ -528,3 +528,23 @@ def test_gemm_nt_multi_problem_launch_equals_separate_launches():
     got2 = gemm.wgrad_nt_multi([(dy, x, None) for dy, x, _ in reqs[:5]], splits=own)      # given splits, fresh destinations
     for (dy, x, _), o in zip(reqs[:5], got2):
         assert torch.equal(o, gemm.wgrad_nt(dy, x))
+
+
+def test_stacked_transposes_one_launch_equals_one_per_group():
+    """gemm.stacked_transposes (gm3d_transpose_bf16_multi: the four transposed weight shadows of a stack in one launch) == one
+    stacked_transpose per group, for weights at a constant stride inside one flat buffer (the optimizer's bf16 shadow)."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(2)
+    nblk = 4
+    shapes = [(384, 1536), (384, 384), (1536, 384), (1152, 384)]
+    per = sum(a * b for a, b in shapes) + 640
+    flat = torch.randn(nblk * per, device="cuda", generator=g).bfloat16()
+    groups, off = [], 0
+    for a, b in shapes:
+        groups.append([flat[i * per + off:i * per + off + a * b].view(a, b) for i in range(nblk)])
+        off += a * b
+    got = gemm.stacked_transposes(groups)
+    for ws, o in zip(groups, got):
+        assert torch.equal(o, torch.stack(ws).transpose(1, 2).contiguous())
+    one = gemm.stacked_transposes([groups[0]])            # a single group: the per-group path
+    assert torch.equal(one[0], got[0])
