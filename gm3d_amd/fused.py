@@ -280,6 +280,29 @@ def _wgrad_many(reqs):
     return [_wgrad_batched(dy, x, out) for dy, x, out in reqs]
 
 
+def defer_wgrad(dy, x, w=None):
+    """dW (N,K) f32 = dy (R,N)^T @ x (R,K) for a layer OUTSIDE the block stacks (heads, positional MLP), w its weight parameter.
+    Inside the engine's backward region, when w has a slot in the optimizer's flat gradient buffer and no gradient yet (nothing will
+    read or add to the result before the region ends), the product joins the stacks' one-launch weight gradients and lands in the slot;
+    elsewhere, or when the kernel does not take the shape, it is computed now."""
+    reg = _ASYNC_WGRAD
+    if (reg["stream"] is not None and gemm.MULTI_WGRAD and DEFER_HEAD_WGRAD and w is not None and w.grad is None and dy.dim() == 2
+            and dy.is_contiguous() and x.is_contiguous()):
+        from .optim import grad_slots, ENABLE_DIRECT_WGRAD
+        slot = grad_slots.get(w) if ENABLE_DIRECT_WGRAD else None
+        if slot is not None and slot.is_contiguous() and slot.numel() == dy.shape[1] * x.shape[1]:
+            out = slot.view(1, dy.shape[1], x.shape[1])
+            if gemm.wgrad_multi_ok(dy.unsqueeze(0), x.unsqueeze(0), out):
+                reg["deferred"].append(((dy, x), [(dy.unsqueeze(0), x.unsqueeze(0), out)]))
+                return out[0]
+    from .embed import splitk_wgrad
+    return splitk_wgrad(dy, x)
+
+
+DEFER_HEAD_WGRAD = False  # the heads' / positional MLP's weight gradients inside the stacks' one-launch form (fused.defer_wgrad): measured
+#                           0.4 % slower (7.43 vs 7.39 ms same-box): three small products are cheaper where they stand than as extra tiles there
+
+
 def _run_deferred(reg, own=()):
     """the deferred stacks' weight-gradient requests, plus `own` (the calling stack's), on the current stream -> the results of `own`"""
     jobs, reg["deferred"] = reg["deferred"], []

@@ -13,6 +13,11 @@ import torch
 
 from ._capi import lib
 from .embed import _c32, _finish, colsum, splitk_wgrad
+
+
+def _defer_wgrad(dy, x, w=None):
+    from . import fused
+    return fused.defer_wgrad(dy, x, w)
 from .fused import weight_cache
 from . import gemm
 from .ops import _launch, _ptr, _stream, _DT
@@ -71,9 +76,9 @@ class LinearBiasFn(torch.autograd.Function):
             N, K = W.shape
             R = dy2.shape[0]
             db = colsum(dy2, adt) if ctx.has_bias else None
-            if (adt == torch.bfloat16 and N < 128 and K % 128 == 0
+            if (adt == torch.bfloat16 and N < 128 and K % 128 == 0 and not gemm.RAGGED
                     and gemm.wgrad_supported(dy2.new_empty(1, R, 128), x2.unsqueeze(0))):
-                # narrow layer (N = 96): dy and W^T zero-padded to one 128-wide tile, shared by both products
+                # narrow layer (N = 96) without the ragged-width kernels: dy and W^T zero-padded to one 128-wide tile, shared by both products
                 pad = torch.empty(R, 128, dtype=adt, device=dy2.device)
                 _launch("gm3d_pad_cols", {"R": R, "N": N}, lib.gm3d_pad_cols, _ptr(dy2), dy2.stride(0), R, N, _ptr(pad), 128, _DT[adt], _stream())
                 wt = torch.zeros(K, 128, dtype=adt, device=dy2.device)
@@ -82,7 +87,7 @@ class LinearBiasFn(torch.autograd.Function):
                 dW = gemm.wgrad_nt(pad.unsqueeze(0), x2.unsqueeze(0))[0][:N].contiguous().reshape(w.shape)
                 return dx, dW, db, None
             dx = gemm.mm_nn(dy2, W).view(ctx.shp).to(ctx.xdt)
-            dW = splitk_wgrad(dy2, x2).reshape(w.shape)
+            dW = _defer_wgrad(dy2, x2, w).reshape(w.shape)
             return dx, dW, db, None
 
 
@@ -317,7 +322,7 @@ class PosEmbedFn(torch.autograd.Function):
             B, G, R, C = ctx.dims
             d = dout.reshape(R, -1).to(adt).contiguous()
             W1 = weight_cache.get(w1, adt)
-            dW1 = splitk_wgrad(d, h)
+            dW1 = _defer_wgrad(d, h, w1)
             db1 = colsum(d, adt)
             dh = gemm.mm_nn(d, W1).contiguous()
             nrows = lib.gm3d_embed_partial_rows(3, R, C)
@@ -416,7 +421,7 @@ class LossPredHeadFn(torch.autograd.Function):
                     _ptr(dy), _ptr(dt), G, K, C, float(slope), _DT[adt], _stream())
             W0 = weight_cache.get(w0, adt).reshape(C, Cin)
             dx = gemm.mm_nn(dy, W0).view(B, L, Cin).to(ctx.xdt)
-            dW0 = splitk_wgrad(dy, x2).reshape(w0.shape)
+            dW0 = _defer_wgrad(dy, x2, w0).reshape(w0.shape)
             db0 = colsum(dt, torch.float32)
             return dx, dW0, db0, s2, s1, dW1, db1, None, None, None, None
 
