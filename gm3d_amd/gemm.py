@@ -415,6 +415,7 @@ def wgrad_nt(dy, x, out=None, splits=None):
     return out
 
 
+MULTI_TARGET_WGS = 512    # ... and for a launch with few tiles: the workgroup count its row splits aim at
 MULTI_SPLITS_MAX = 2      # with MULTI_WGRAD: cap on the row splits of the 8192-row problems (1 for <= 4096 rows) when the whole launch has >= 768 tiles:
 #                           the launch as a whole fills the chip, so a problem needs splits only against a long tail (0 = keep each problem's own)
 MULTI_WGRAD = True        # the weight gradients of several stacks as ONE launch (+ one slab-sum launch): gm3d_gemm_nt_bf16_multi.  With each
@@ -442,7 +443,7 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
     outs, parts, spl = [], [], []
     tiles = [r[0].shape[0] * ((r[0].shape[2] + 127) // 128) * ((r[1].shape[2] + 127) // 128) for r in reqs]
     tiles_all = sum(tiles)
-    rows_target = max(512, sum(t_ * r[0].shape[1] for t_, r in zip(tiles, reqs)) // 512)
+    rows_target = max(512, sum(t_ * r[0].shape[1] for t_, r in zip(tiles, reqs)) // MULTI_TARGET_WGS)
     for dy, x, out in reqs:
         nb, R, N = dy.shape
         K = x.shape[2]
