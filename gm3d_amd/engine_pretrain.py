@@ -424,6 +424,20 @@ def _const_scalar(device, value):
     return c
 
 
+_false_cache = {}
+
+
+def _all_false(B, L, device):
+    """(B,L) bool zeros (the teacher's all-visible mask), cached per shape like _arange_ids; created outside stream capture only."""
+    key = (B, L, device.type, device.index)
+    t = _false_cache.get(key)
+    if t is None:
+        t = torch.zeros(B, L, dtype=torch.bool, device=device)
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _false_cache[key] = t
+    return t
+
+
 def backward_and_collect(total, raw, optimizer, grad_sync, accum=1, accum_first=True, accum_last=True, async_w=True):
     """zero (first micro-batch of the window) -> backward -> gradients where the update / all-reduce expects them.
     total: the scalar objective (already divided by accum), or a tuple of scalar losses whose sum / accum is the objective.
@@ -478,7 +492,7 @@ def step_forward_backward(model, model_ema, samples, epoch, args, grad_sync=None
         weight_cache.refresh()       # ONE multi-tensor cast of all GEMM weights per model per step
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
     B = samples.shape[0]
-    visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
+    visible_mask = _all_false(B, L, samples.device)      # read only
     with amp:
         with torch.no_grad():
             group = teacher.group_divider(samples)  # FPS + KNN once; shared with the student
@@ -752,7 +766,7 @@ class SegmentedDDPStep:
             weight_cache.refresh()
         amp = torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()
         B = samples.shape[0]
-        visible_mask = torch.zeros(B, L, dtype=torch.bool, device=samples.device)
+        visible_mask = _all_false(B, L, samples.device)      # read only
         with amp:
             with torch.no_grad():
                 group = teacher.group_divider(samples)
