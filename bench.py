@@ -2,9 +2,10 @@
 """Benchmark of the hot path: one Point-MAE + GeoMask3D pretrain step (teacher fwd -> guided mask ->
 student fwd/bwd -> Chamfer + ranking loss -> clip -> AdamW -> EMA) per "step", on synthetic clouds.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher's environment: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+--gpus that disagrees with WORLD_SIZE, or exceeds the visible GPUs, exits non-zero: the line never claims ranks that did not run.
 
 Workload (BASELINE.json configs[1]/[2]): B=128 clouds per GPU, N=1024 points, G=64 groups, k=32, d=384,
 depth 12 (+2x4 decoder blocks), bf16 autocast, random-init weights (seed 0), clouds ~ U[-1,1]^3 centred and
@@ -273,6 +274,84 @@ def secondary(device, replays=10):
     return out
 
 
+import contextlib  # noqa: E402
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL and gloo print banners on fd 1 when their first communicator comes up: keep stdout for the ONE JSON line."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv, dry_run=False):
+    """`python bench.py --gpus N` without a launcher's environment: start N fresh rank processes of this file (one per GPU;
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* as torch.distributed.run would set them), relay rank 0's ONE JSON line, exit with
+    the worst return code.  The parent never initialises HIP (device_count() does not, on this image).  What the reference does
+    with torch.distributed.launch / SLURM variables (P/main_pretrain_multi_gpu.py:166-177,309-311, P/util/misc.py:215-247).
+    A rank that dies takes the others down with it (exact PIDs) instead of leaving them in the rendezvous."""
+    import subprocess
+    have = torch.cuda.device_count()
+    if not dry_run and n > have:
+        print("bench.py: --gpus %d but only %d GPU(s) visible: refusing to measure fewer ranks than asked for" % (n, have), file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0's stdout is ours (the JSON line); the other ranks print nothing on stdout by contract: route it to stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    worst, live, ours = 0, set(range(n)), set()          # ours: ranks this launcher terminated (their -15 is not a result)
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0 and r not in ours:
+                print("bench.py: rank %d exited with %d" % (r, rc), file=sys.stderr)
+                worst = max(worst, rc if rc > 0 else 128 - rc)
+                for o in live:
+                    ours.add(o)
+                    procs[o].terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def dry_run_rank(rank, world):
+    """--launch-dry-run: the rank environment without a GPU -- gloo group, all-reduce of the rank numbers, one JSON line."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    if os.environ.get("GM3D_DRYRUN_FAIL_RANK") == str(rank):      # test hook: a rank that dies before the rendezvous
+        sys.exit(7)
+    with stdout_to_stderr():
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        n = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": n, "rank_sum": float(t), "backend": "gloo"}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -290,11 +369,26 @@ def main():
                          "(graph mode cannot overlap it with backward anyway, and one large ring all-reduce has the least fixed cost)")
     ap.add_argument("--no-graph", action="store_true",
                     help="eager launches instead of hipGraph replay (the step is ~1000 launches: eager is host-bound)")
+    ap.add_argument("--launch-dry-run", action="store_true",
+                    help="start the ranks exactly as a real run would, but each only joins a gloo group, all-reduces its rank "
+                         "number and exits (no GPU, no kernels): the CPU test of the launch path")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher above us: be the launcher (before any GPU call)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.launch_dry_run))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if args.gpus != world:
+        # never measure a different number of ranks than the line would claim
+        sys.exit("bench.py: --gpus %d disagrees with WORLD_SIZE %d" % (args.gpus, world))
+    if args.launch_dry_run:
+        return dry_run_rank(rank, world)
+    if local_rank >= torch.cuda.device_count():
+        sys.exit("bench.py: LOCAL_RANK %d but %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     # GM3D_FORCE_DIST=1: take the data-parallel code path (RCCL process group, bucketed all-reduce, two graphs) with a
     # single rank -- lets a one-GPU box rehearse exactly what the N>1 launch runs
     use_dist = world > 1 or os.environ.get("GM3D_FORCE_DIST") == "1"
@@ -302,22 +396,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
-        # RCCL prints a version banner on stdout when its first communicator comes up: keep stdout for the ONE JSON line
-        sys.stdout.flush()
-        saved_stdout = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_stdout, 1)
-            os.close(saved_stdout)
     else:
         torch.cuda.set_device(0)
-    if args.gpus != world and rank == 0 and world > 1:
-        print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
     device = torch.device("cuda", local_rank if use_dist else 0)
 
     from gm3d_amd import engine_pretrain as E
@@ -476,6 +560,7 @@ def main():
             "value": args.batch * world * args.steps / dt,
             "unit": "clouds/s",
             "n_gpus": world,
+            "rccl_ranks": dist.get_world_size() if use_dist else None,      # the process group's own count (None: no group, one GPU)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -506,9 +591,13 @@ def main():
         }
         if not args.no_secondary and not use_dist and not args.fp32:
             line["secondary"] = secondary(device)
-        if not args.no_cpu_baseline:
+        # N=1 only: at N>1 the other ranks would sit in a GPU barrier while rank 0 does 20 s of host work
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.cpu_batch, args.cpu_steps)
-        print(json.dumps(line))
+        elif world > 1:
+            line["cpu_baseline"] = None
+            line["cpu_baseline_note"] = "measured at N=1 only (rank 0 of the 1-GPU run)"
+        print(json.dumps(line), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
