@@ -912,6 +912,8 @@ def run_epoch(data_loader, optimizer, device, epoch, args, eager_step, capture, 
     Learning rate: per iteration, set only at the start of an accumulation window (P/:72-73)."""
     n_iter = len(data_loader)
     accum = getattr(args, "accum_iter", 1)
+    if model_key is None:          # a weak dictionary cannot key on None: the warm-up count then belongs to the optimizer
+        model_key = optimizer
     # P/engine_pretrain.py:62 `optimizer.zero_grad()` at the start of every epoch: micro-batches of a window the previous epoch
     # left unfinished (len(data_loader) % accum_iter != 0) are discarded, not added to this epoch's first update
     if getattr(optimizer, "GA", None) is not None:

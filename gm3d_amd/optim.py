@@ -290,13 +290,17 @@ class FlatAdamWEma(torch.optim.Optimizer):
         self._gathered = False
         g = self.param_groups[0]
         if self.ema is not None:
-            # the EMA weight on the device: written only when it changes (once per epoch).  Inside a stream capture the fill is
-            # captured whenever the device may not hold the value yet, and the host-side record is left alone (nothing executes there)
+            # the EMA weight on the device: eager steps write it only when it changes (once per epoch).  A captured step always
+            # carries its own fill -- a graph must not depend on what an earlier eager step left on the device -- and forgets the
+            # host-side record, since its replays change the device value behind the host's back (a later eager step
+            # at the recorded decay would otherwise skip the fill and run with the graph's weight)
             w = 1.0 - float(self.ema.decay)
-            if getattr(self, "_ema_w_host", None) != w:
+            if self.ema_w_dev.is_cuda and torch.cuda.is_current_stream_capturing():
                 self.ema_w_dev.fill_(w)
-                if not (self.ema_w_dev.is_cuda and torch.cuda.is_current_stream_capturing()):
-                    self._ema_w_host = w
+                self._ema_w_host = None
+            elif getattr(self, "_ema_w_host", None) != w:
+                self.ema_w_dev.fill_(w)
+                self._ema_w_host = w
         check(lib.gm3d_adamw_ema_flat_step_lrd(
             _ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS), _ptr(self.ES), self.n,
             self.n_decay, _ptr(self.lr_dev), _ptr(self.LS), float(g["weight_decay"]), float(g["betas"][0]),

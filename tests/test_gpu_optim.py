@@ -133,3 +133,51 @@ def test_state_dict_round_trip_by_parameter_name_and_stale_gradient_guard():
     oa.step()
     slot = {id(p): v for p, v in oa.flat_grad_views()}
     assert float(slot[id(a[2].weight)].abs().max()) == 0.0 and float(slot[id(a[0].weight)].abs().max()) > 0
+
+
+def test_ema_weight_survives_graph_replays_at_another_decay():
+    """eager step at decay A, captured steps at decay B replayed, eager step at decay A again -- the EMA
+    parameters must equal those of an all-eager twin (the device-side EMA weight must not be left at the graph's value)."""
+    from gm3d_amd import engine_pretrain as E
+    torch.manual_seed(0)
+
+    def make():
+        torch.manual_seed(1)
+        net = torch.nn.Sequential(torch.nn.Linear(32, 64), torch.nn.LayerNorm(64), torch.nn.Linear(64, 16)).cuda()
+        ema = E.ModelEma(net, decay=0.5)
+        opt = E.build_optimizer(net, lr=1e-2, weight_decay=0.05, flat=True, model_ema=ema, clip_grad=1.0)
+        return net, ema, opt
+
+    grads = [torch.randn(64 * 32 + 64 + 64 + 64 + 16 * 64 + 16, device="cuda") for _ in range(6)]
+    decays = [0.5, 0.9, 0.9, 0.9, 0.5, 0.9]
+
+    def run(graphed):
+        net, ema, opt = make()
+        assert opt.G.numel() >= grads[0].numel()
+        static_g = torch.zeros_like(opt.G)
+        graph = None
+        for i, (g, d) in enumerate(zip(grads, decays)):
+            ema.decay = d
+            static_g.zero_()
+            static_g[:g.numel()].copy_(g)
+            if graphed and d == 0.9:
+                if graph is None:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        opt.G.copy_(static_g)
+                        opt.mark_grads_filled()
+                        E.step_update(net, ema, opt)
+                else:
+                    graph.replay()
+            else:
+                opt.G.copy_(static_g)
+                opt.mark_grads_filled()
+                E.step_update(net, ema, opt)
+        torch.cuda.synchronize()
+        return opt.P.clone(), opt.E.clone()
+
+    p0, e0 = run(False)
+    p1, e1 = run(True)
+    assert torch.equal(p0, p1)
+    assert torch.equal(e0, e1)

@@ -194,3 +194,22 @@ def test_drop_path_scales_are_drawn_per_site_and_consumed_in_plan_order(M):
     c = M.drop_path_scales(4, [0.2], True, dev)                                   # no plan left: drawn on the spot
     assert c[0].shape == (4,)
     assert M.drop_path_scales(4, [0.2], False, dev) == [None]                      # eval mode: inactive
+
+
+def test_run_epoch_without_a_model_key():
+    """run_epoch's warm-up counter is a weak dictionary; callers that omit model_key must not hit a TypeError."""
+    from gm3d_amd import engine_pretrain as E
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([w], lr=0.1)
+    args = SimpleNamespace(accum_iter=1, lr=1e-3, min_lr=0.0, warmup_epochs=1, epochs=4)
+    seen = []
+
+    def eager_step(samples, it):
+        seen.append(it)
+        z = samples.sum() * 0
+        return {"loss": z + 1.0, "loss_learn": z + 0.5, "loss_mse": z, "loss_chfr": z + 2.0, "grad_norm": z + 3.0}
+
+    loader = [torch.ones(2, 8, 3) for _ in range(4)]
+    stats = E.run_epoch(loader, opt, torch.device("cpu"), 0, args, eager_step, capture=lambda ex: None, print_freq=100)
+    assert seen == [0, 1, 2, 3]
+    assert abs(stats["loss"] - 1.5) < 1e-6 and abs(stats["grad_norm"] - 3.0) < 1e-6 and stats["replayed_iters"] == 0
