@@ -250,8 +250,9 @@ def secondary(device, replays=10):
             P.pretrain_step(model, ema, opt, pool[i].clone(), 100, ma)
         torch.cuda.synchronize()
         static_in = pool[0].clone()
+        from gm3d_amd import streams
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with streams.capture(g):
             res = P.pretrain_step(model, ema, opt, static_in, 100, ma)
 
         def step(i):

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
+from . import streams
 from .engine_pretrain import train_transforms
 
 POINT_ALL = {1024: 1200, 2048: 2400, 4096: 4800, 8192: 8192}
@@ -171,11 +172,11 @@ class GraphedFinetuneStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with streams.capture(self.graph):
             self.out = self._body()
         if self.overlap:
             self.sample_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.sample_graph, stream=self.sstream):
+            with streams.capture(self.sample_graph, stream=self.sstream):
                 self.staged.copy_(sample_points(self.points, npoints, subset=self.subset))
             torch.cuda.synchronize()
 

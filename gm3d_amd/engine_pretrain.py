@@ -20,6 +20,8 @@ from contextlib import nullcontext
 import torch
 import torch.distributed as dist
 
+from . import streams
+
 # --------------------------------------------------------------------------- GEMM selection
 def enable_tuned_gemms(tune_missing=False):
     """Point PyTorch's TunableOp at the hipBLASLt solution choices recorded for this step's GEMM shapes on gfx950
@@ -636,15 +638,15 @@ class GraphedPretrainStep:
         mode = "thread_local" if dist.is_initialized() else "global"
         if not two:
             self.graph2 = None
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            with streams.capture(self.graph, capture_error_mode=mode):
                 self.out = whole(self.static_in)
         else:
-            with torch.cuda.graph(self.graph, capture_error_mode=mode):
+            with streams.capture(self.graph, capture_error_mode=mode):
                 self.out = fwd_bwd(model, model_ema, self.static_in, epoch, args, optimizer=optimizer, **kw)
             self.graph2 = torch.cuda.CUDAGraph()
             if hasattr(optimizer, "mark_grads_filled"):
                 optimizer.mark_grads_filled()       # G is complete when this graph runs (gathered / collected / all-reduced)
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
+            with streams.capture(self.graph2, pool=self.graph.pool(), capture_error_mode=mode):
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 
     def _collect(self):
@@ -729,12 +731,12 @@ class SegmentedDDPStep:
             import os
             mode = "thread_local" if dist.is_initialized() else "global"
             self.graphs = [torch.cuda.CUDAGraph() for _ in range(4)]
-            with torch.cuda.graph(self.graphs[0], capture_error_mode=mode):
+            with streams.capture(self.graphs[0], capture_error_mode=mode):
                 self.out = self._phase1(self.static_in)
             for k, phase in ((1, self._phase2), (2, self._phase3)):
-                with torch.cuda.graph(self.graphs[k], pool=self.graphs[0].pool(), capture_error_mode=mode):
+                with streams.capture(self.graphs[k], pool=self.graphs[0].pool(), capture_error_mode=mode):
                     phase()
-            with torch.cuda.graph(self.graphs[3], pool=self.graphs[0].pool(), capture_error_mode=mode):
+            with streams.capture(self.graphs[3], pool=self.graphs[0].pool(), capture_error_mode=mode):
                 self.opt.mark_grads_filled()
                 self.out["grad_norm"] = step_update(model, model_ema, optimizer)
 

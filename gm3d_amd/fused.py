@@ -21,6 +21,7 @@ import torch
 
 from ._capi import lib
 from . import gemm
+from . import streams as _streams
 from .ops import _launch, _ptr, _stream, _DT
 
 LNC = 384
@@ -343,7 +344,7 @@ class async_wgrad:
                 _run_deferred(reg)
             reg["deferred"] = []
         if ws is not None and used:
-            torch.cuda.current_stream().wait_stream(ws)
+            _streams.join(ws)
         return False
 
 
@@ -598,7 +599,7 @@ class TransformerStackFn(torch.autograd.Function):
             gw2, gw1, gwp, gwq = slots
         else:
             if ws is not None and nblk >= reg["min_blocks"]:
-                ws.wait_stream(torch.cuda.current_stream())
+                _streams.fork(ws, who="fused.TransformerStackFn.backward: weight-gradient stream (async_wgrad region)")
                 reg["used"] = True
                 for t in (DO, GG, DF, H2, DP, A, DQ, H1):
                     t.record_stream(ws)
@@ -646,7 +647,7 @@ def run_stack(blocks, final_norm, x, pos, training):
         outs = [None] * ns
         streams = [main] + [_split_stream(x.device, j) for j in range(1, ns)]
         for side in streams[1:]:
-            side.wait_stream(main)
+            _streams.fork(side, main, who="fused.run_stack: parallel inference chain (NOGRAD_SPLIT)")
             x.record_stream(side)
             pos.record_stream(side)
         if LOCKSTEP:
@@ -678,7 +679,7 @@ def run_stack(blocks, final_norm, x, pos, training):
                                                        final_norm.bias, *params)
             outs[0] = TransformerStackFn.apply(x[:h], pos[:h], meta, final_norm.weight, final_norm.bias, *params)
         for j in range(1, ns):
-            main.wait_stream(streams[j])
+            _streams.join(streams[j], main)
             outs[j].record_stream(main)
         return out if LOCKSTEP else torch.cat(outs, dim=0)
     return TransformerStackFn.apply(x, pos, meta, final_norm.weight, final_norm.bias, *params)

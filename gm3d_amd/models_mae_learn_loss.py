@@ -25,6 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from . import streams
 from .ops import ChamferDistanceL1, ChamferDistanceL2  # noqa: F401  (re-exported like the reference imports)
 
 
@@ -497,7 +498,7 @@ class MaskedAutoencoderViT(nn.Module):
         if PARALLEL_DECODERS and need_pix_pred and x_full.is_cuda:
             main = torch.cuda.current_stream()
             side = _decoder_stream(x_full.device)
-            side.wait_stream(main)
+            streams.fork(side, main, who="models_mae_learn_loss: loss-prediction decoder branch (PARALLEL_DECODERS)")
             with torch.cuda.stream(side):     # the loss-prediction branch: decoder AND its head
                 loss_pred_ = self.MAE_decoder_loss_pred(x_full, pos_full, N)
                 loss_pred_out = self._loss_pred_head(loss_pred_)
@@ -513,7 +514,7 @@ class MaskedAutoencoderViT(nn.Module):
             else:
                 rebuild_points = F.linear(x_rec, c.weight.squeeze(-1), c.bias)  # B L 96
         if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
+            streams.join(side)
             loss_pred_out.record_stream(torch.cuda.current_stream())
         else:
             loss_pred_out = self._loss_pred_head(self.MAE_decoder_loss_pred(x_full, pos_full, N))

@@ -168,8 +168,7 @@ def test_ema_weight_survives_graph_replays_at_another_decay():
                         opt.G.copy_(static_g)
                         opt.mark_grads_filled()
                         E.step_update(net, ema, opt)
-                else:
-                    graph.replay()
+                graph.replay()                  # (a capture executes nothing: the first captured step runs as a replay too)
             else:
                 opt.G.copy_(static_g)
                 opt.mark_grads_filled()
