@@ -124,10 +124,14 @@ __global__ __launch_bounds__(256) void mattn_fwd_bf16_kernel(const bf16_t* __res
     for (int d = 0; d < DT; ++d) o[d] = mzero16();
     const int cb = 16 * ((lane >> 4) & 1);
     for (int kt = 0; kt < NK; ++kt) {
+        // a key tile that is blocked for every query of this wave's tile contributes exp(-inf) = 0 to every sum and leaves the
+        // running maximum alone: skipping it changes no bit.  With the visible tokens moved to the front of the cloud
+        // (gm3d_partition_visible) the filler rows behind them form such tiles, as keys and as queries.
+        const unsigned mw = mask_word(mrow, q_ok, kt, T);
+        if (__ballot(mw != 0xffffffffu) == 0ull) continue;
         mf32x16 st = mzero16();
 #pragma unroll
         for (int s = 0; s < KS; ++s) st = MMFMA(I::row(Ki, 32 * kt + r, 2 * s + hh), fq[s], st);
-        const unsigned mw = mask_word(mrow, q_ok, kt, T);
         float tm = -INFINITY;
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
@@ -235,13 +239,14 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
 #pragma unroll
         for (int s = 0; s < KS; ++s) { fk[s] = I::row(Ki, row, 2 * s + hh); fv[s] = I::row(Vi, row, 2 * s + hh); }
         for (int qt = 0; qt < NT; ++qt) {
+            const unsigned mw = mask_word(mrow, row_ok, qt, T);
+            if (__ballot(mw != 0xffffffffu) == 0ull) continue;        // every pair of this tile blocked: p = 0 throughout (exact)
             mf32x16 s = mzero16(), dp = mzero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = MMFMA(I::row(Qi, 32 * qt + r, 2 * ks + hh), fk[ks], s);
                 dp = MMFMA(I::row(Di, 32 * qt + r, 2 * ks + hh), fv[ks], dp);
             }
-            const unsigned mw = mask_word(mrow, row_ok, qt, T);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int q = 32 * qt + mcrow(g, hh);
@@ -266,13 +271,14 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
         for (int s = 0; s < KS; ++s) { fq[s] = I::row(Qi, row, 2 * s + hh); fd[s] = I::row(Di, row, 2 * s + hh); }
         const float lq = Ls[row], dq_ = Del[row];
         for (int kt = 0; kt < NT; ++kt) {
+            const unsigned mw = mask_word(mrow, row_ok, kt, T);
+            if (__ballot(mw != 0xffffffffu) == 0ull) continue;
             mf32x16 s = mzero16(), dp = mzero16();
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 s = MMFMA(I::row(Ki, 32 * kt + r, 2 * ks + hh), fq[ks], s);
                 dp = MMFMA(I::row(Vi, 32 * kt + r, 2 * ks + hh), fd[ks], dp);
             }
-            const unsigned mw = mask_word(mrow, row_ok, kt, T);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const float p = ((mw >> mcrow(g, hh)) & 1u) ? 0.f : __expf(s[g] * scale - lq);

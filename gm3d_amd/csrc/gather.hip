@@ -109,3 +109,107 @@ extern "C" int gm3d_gather_rows_bwd(const void* dy, const int* off, const int* l
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
+
+// ===================================================================== visible-first token order of a masked level
+// The student's pass of the hierarchical encoder keeps only some tokens of a level visible (multi-scale masking:
+// gm3d_amd/point_m2ae.py back_project; mask ratio 0.8 of Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99).  Block stacks work on
+// the visible tokens moved to the front of every cloud (stable order), cut to a static bound Tc where one is known: the rows behind
+// the visible count are padding that the attention mask blocks -- whole key / query tiles of it are skipped, and with Tc < T the
+// GEMM / LayerNorm passes shrink as well.
+//
+// gm3d_partition_visible: one workgroup per cloud.  masked (B, T) bytes (non-zero = masked), Tc <= T:
+//   perm_c (B, Tc) int32   token at compact slot j: the visible tokens in ascending token order, then masked ones (filler rows)
+//   perm_v (B, Tc) int32   the same with -1 in the filler slots
+//   inv_v  (B, T)  int32   compact slot of token t if it is visible (and fits below Tc), else -1
+//   inv_m  (B, T)  int32   t if token t is masked, else -1   (the rows a merge takes from the un-encoded side)
+//   vis_c  (B, Tc) bytes   1 for slots that hold a visible token
+//   overflow (1) int32     set to 1 when some cloud has more than Tc visible tokens (never cleared here)
+namespace gm3d {
+
+__global__ __launch_bounds__(1024) void partition_visible_kernel(const unsigned char* __restrict__ masked, int T, int Tc,
+                                                                 int* __restrict__ perm_c, int* __restrict__ perm_v,
+                                                                 int* __restrict__ inv_v, int* __restrict__ inv_m,
+                                                                 unsigned char* __restrict__ vis_c, int* __restrict__ overflow) {
+    __shared__ int wsum[16];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const bool vis = t < T && masked[(size_t)b * T + t] == 0;
+    const unsigned long long bal = __ballot(vis);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0, cnt = 0;
+    const int nw = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < nw; ++k) {
+        const int c = wsum[k];
+        if (k < w) base += c;
+        cnt += c;
+    }
+    if (t >= T) return;
+    const int nvis_before = base + before;
+    const int slot = vis ? nvis_before : cnt + (t - nvis_before);
+    if (slot < Tc) {
+        perm_c[(size_t)b * Tc + slot] = t;
+        perm_v[(size_t)b * Tc + slot] = vis ? t : -1;
+        vis_c[(size_t)b * Tc + slot] = vis ? 1 : 0;
+    }
+    inv_v[(size_t)b * T + t] = (vis && slot < Tc) ? slot : -1;
+    inv_m[(size_t)b * T + t] = vis ? -1 : t;
+    if (t == 0 && cnt > Tc) *overflow = 1;
+}
+
+// out (B, T, C) rows picked per row:  idx[b][t] >= 0 -> a[b][idx[b][t]][:]  (a is (B, Ta, C)),  else alt[b][t][:] (alt (B, T, C)) or
+// zeros when alt is NULL.  One thread per 16 bytes (C * sizeof(T) % 16 == 0) or per element otherwise.
+template <class V>
+__global__ __launch_bounds__(256) void select_rows_kernel(const V* __restrict__ a, const int* __restrict__ idx, const V* __restrict__ alt,
+                                                          V* __restrict__ out, int Ta, int T, int cpr, long long total) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long row = g / cpr;                // b * T + t
+        const int c = (int)(g - row * cpr);
+        const int b = (int)(row / T);
+        const int i = idx[row];
+        V v;
+        if (i >= 0) v = a[((size_t)b * Ta + i) * cpr + c];
+        else if (alt) v = alt[(size_t)row * cpr + c];
+        else v = V{};
+        out[(size_t)row * cpr + c] = v;
+    }
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_partition_visible(const unsigned char* masked, int B, int T, int Tc, int* perm_c, int* perm_v, int* inv_v, int* inv_m,
+                                      unsigned char* vis_c, int* overflow, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!masked || !perm_c || !perm_v || !inv_v || !inv_m || !vis_c || !overflow || B < 0 || T < 1 || Tc < 1 || Tc > T) return GM3D_EINVAL;
+    if (T > 1024) return GM3D_EUNSUPPORTED;
+    if (B == 0) return GM3D_OK;
+    const int threads = (T + 63) / 64 * 64;
+    hipLaunchKernelGGL(partition_visible_kernel, dim3(B), dim3(threads), 0, (hipStream_t)stream, masked, T, Tc, perm_c, perm_v, inv_v, inv_m,
+                       vis_c, overflow);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_select_rows(const void* a, const int* idx, const void* alt, void* out, int B, int Ta, int T, int C, int elem_bytes,
+                                gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!a || !idx || !out || B < 0 || Ta < 1 || T < 1 || C < 1 || (elem_bytes != 2 && elem_bytes != 4)) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long row_bytes = (long long)C * elem_bytes;
+    const bool wide = row_bytes % 16 == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!alt || (uintptr_t)alt % 16 == 0);
+    const int cpr = wide ? (int)(row_bytes / 16) : C;
+    const long long total = (long long)B * T * cpr;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (wide)
+        hipLaunchKernelGGL(select_rows_kernel<uint4>, dim3(grid), dim3(256), 0, st, (const uint4*)a, idx, (const uint4*)alt, (uint4*)out, Ta, T,
+                           cpr, total);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(select_rows_kernel<unsigned>, dim3(grid), dim3(256), 0, st, (const unsigned*)a, idx, (const unsigned*)alt,
+                           (unsigned*)out, Ta, T, cpr, total);
+    else
+        hipLaunchKernelGGL(select_rows_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, (const unsigned short*)a, idx,
+                           (const unsigned short*)alt, (unsigned short*)out, Ta, T, cpr, total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

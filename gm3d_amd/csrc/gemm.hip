@@ -306,9 +306,9 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int rr = tr + 32 * p;
-        float v[8];
-        V8<bf16_t>::load(s + (size_t)(r0 + rr) * cols + c0 + tc, v);
-#pragma unroll
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (r0 + rr < rows && c0 + tc < cols) V8<bf16_t>::load(s + (size_t)(r0 + rr) * cols + c0 + tc, v);     // rows, cols % 8 == 0: a chunk is
+#pragma unroll                                                                                                 // inside or outside as a whole
         for (int e = 0; e < 8; ++e) tile[rr][tc + e] = (bf16_t)v[e];
     }
     __syncthreads();
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __res
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)tile[tc + e][cc];
-        V8<bf16_t>::store(d + (size_t)(c0 + cc) * rows + r0 + tc, v);
+        if (c0 + cc < cols && r0 + tc < rows) V8<bf16_t>::store(d + (size_t)(c0 + cc) * rows + r0 + tc, v);
     }
 }
 
@@ -343,7 +343,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TrMulti m) {
     for (int j = 1; j < TR_MAXP; ++j)
         if (j < m.count && (int)blockIdx.x >= m.p[j].first) q = m.p[j];
     int local = (int)blockIdx.x - q.first;
-    const int nx = q.cols / 64, ny = q.rows / 64;
+    const int nx = (q.cols + 63) / 64, ny = (q.rows + 63) / 64;
     const int bx = local % nx; local /= nx;
     const int by = local % ny;
     const int bz = local / ny;
@@ -354,8 +354,8 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TrMulti m) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int rr = tr + 32 * p;
-        float v[8];
-        V8<bf16_t>::load(s + (size_t)(r0 + rr) * q.cols + c0 + tc, v);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (r0 + rr < q.rows && c0 + tc < q.cols) V8<bf16_t>::load(s + (size_t)(r0 + rr) * q.cols + c0 + tc, v);
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[rr][tc + e] = (bf16_t)v[e];
     }
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) void transpose_bf16_multi_kernel(TrMulti m) {
         float v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (float)tile[tc + e][cc];
-        V8<bf16_t>::store(d + (size_t)(c0 + cc) * q.rows + r0 + tc, v);
+        if (c0 + cc < q.cols && r0 + tc < q.rows) V8<bf16_t>::store(d + (size_t)(c0 + cc) * q.rows + r0 + tc, v);
     }
 }
 
@@ -484,7 +484,7 @@ extern "C" int gm3d_gemm_tn_bf16_lna(const void* U16, const float* stats, const 
 
 extern "C" int gm3d_gemm_tile_rows(int M) { return M < 1 ? 0 : (M + gemm_tile_height(M) - 1) / gemm_tile_height(M); }
 
-// `count` (<= 8) batched transposes dst[j][b][c][r] = src[j][b][r][c] in ONE launch (rows, cols multiples of 64; src batches at
+// `count` (<= 8) batched transposes dst[j][b][c][r] = src[j][b][r][c] in ONE launch (rows, cols multiples of 8; src batches at
 // src_batch_stride[j] elements, dst dense).
 extern "C" int gm3d_transpose_bf16_multi(int count, const void* const* src, void* const* dst, const int* batch, const int* rows, const int* cols,
                                          const long long* src_batch_stride, gm3d_stream_t stream) {
@@ -495,10 +495,10 @@ extern "C" int gm3d_transpose_bf16_multi(int count, const void* const* src, void
     long long first = 0;
     for (int j = 0; j < count; ++j) {
         if (!src[j] || !dst[j] || batch[j] < 1 || rows[j] < 1 || cols[j] < 1 || src_batch_stride[j] < (long long)rows[j] * cols[j]) return GM3D_EINVAL;
-        if (rows[j] % 64 || cols[j] % 64) return GM3D_EUNSUPPORTED;
+        if (rows[j] % 8 || cols[j] % 8) return GM3D_EUNSUPPORTED;
         m.p[j].src = (const bf16_t*)src[j]; m.p[j].dst = (bf16_t*)dst[j]; m.p[j].src_bstride = src_batch_stride[j];
         m.p[j].rows = rows[j]; m.p[j].cols = cols[j]; m.p[j].first = (int)first;
-        first += (long long)(cols[j] / 64) * (rows[j] / 64) * batch[j];
+        first += (long long)((cols[j] + 63) / 64) * ((rows[j] + 63) / 64) * batch[j];
         if (first > 0x7ffffff0LL) return GM3D_EUNSUPPORTED;
     }
     for (int j = count; j < TR_MAXP; ++j) m.p[j] = m.p[0];
@@ -511,9 +511,9 @@ extern "C" int gm3d_transpose_bf16_batched(const void* src, void* dst, int batch
                                            gm3d_stream_t stream) {
     using namespace gm3d;
     if (!src || !dst || batch < 0 || rows < 1 || cols < 1 || src_batch_stride < (long long)rows * cols) return GM3D_EINVAL;
-    if (rows % 64 || cols % 64 || batch > 65535) return GM3D_EUNSUPPORTED;
+    if (rows % 8 || cols % 8 || batch > 65535) return GM3D_EUNSUPPORTED;
     if (batch == 0) return GM3D_OK;
-    hipLaunchKernelGGL(transpose_bf16_kernel, dim3(cols / 64, rows / 64, batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+    hipLaunchKernelGGL(transpose_bf16_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
                        (bf16_t*)dst, rows, cols, (size_t)src_batch_stride);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;

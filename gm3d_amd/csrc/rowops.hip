@@ -234,10 +234,14 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, T* __restrict__ dx,
                                                            float* __restrict__ partial, int R, int C,
                                                            const T* __restrict__ gin, const float* __restrict__ rowscale,
-                                                           int rows_per_sample, T* __restrict__ dy, int nsum) {
+                                                           int rows_per_sample, T* __restrict__ dy, int nsum,
+                                                           T* __restrict__ acc, int acc_mode) {
     // optional residual form: dx = gin + LayerNorm-backward (the gradient of s in ln_plain_fwd_kernel's residual form: it goes to x
     // and z as it stands), dy = rowscale[sample] * dx (the gradient of y; written only when it differs from dx), and with
-    // nsum == 3 a third column-sum block: sum_rows dy = the gradient of ybias (the bias of the Linear that produced y)
+    // nsum == 3 a third column-sum block: sum_rows dy = the gradient of ybias (the bias of the Linear that produced y).
+    // dh == nullptr: no LayerNorm behind the sum (the tail of a block stack) -- dx = gin, nothing of x / mean / rstd / gamma is read.
+    // acc (optional): the running sum of dx over the sites that share an addend (the positional embedding, re-added in front of
+    // every block): acc_mode 1 acc = dx, 2 acc += dx -- one rounding to T per site, like an accumulation of T tensors
     __shared__ float red[8][3 * 512];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, slot = (threadIdx.x >> 6) * 2 + half;
     const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
@@ -247,7 +251,7 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
         const int c = 4 * hl + 128 * i;
-        if (c < C) Quad<float>::load(gamma + c, gm[i]);
+        if (c < C && dh) Quad<float>::load(gamma + c, gm[i]);
         else gm[i][0] = gm[i][1] = gm[i][2] = gm[i][3] = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) sg[i][j] = sb[i][j] = sy[i][j] = 0.f;
@@ -256,17 +260,16 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
         const bool valid = rb + half < R;
         const int r = valid ? rb + half : R - 1;
         const size_t base = (size_t)r * C;
-        const float mu = mean[r], rs = rstd[r];
+        const float mu = dh ? mean[r] : 0.f, rs = dh ? rstd[r] : 0.f;
         float d[NQ][4], xh[NQ][4];
         float a = 0.f, b = 0.f;
 #pragma unroll
         for (int i = 0; i < NQ; ++i) {
             const int c = 4 * hl + 128 * i;
-            if (c < C) {
-                if (dh) Quad<T>::load(dh + base + c, d[i]);
-                else d[i][0] = d[i][1] = d[i][2] = d[i][3] = 0.f;       // no LayerNorm behind the sum: dx = gin
+            if (c < C && dh) {
+                Quad<T>::load(dh + base + c, d[i]);
                 Quad<T>::load(x + base + c, xh[i]);
-            } else {
+            } else {                                                    // (no LayerNorm behind the sum: dx = gin)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { d[i][j] = 0.f; xh[i][j] = mu; }
             }
@@ -288,10 +291,17 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
                 if (gin) Quad<T>::load(gin + base + c, gq);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    o[j] = gq[j] + rs * (d[i][j] * gm[i][j] - m1 - xh[i][j] * m2);
+                    o[j] = dh ? gq[j] + rs * (d[i][j] * gm[i][j] - m1 - xh[i][j] * m2) : gq[j];
                     if (valid) { sg[i][j] += d[i][j] * xh[i][j]; sb[i][j] += d[i][j]; }
                 }
                 if (valid) Quad<T>::store(dx + base + c, o);
+                if (acc_mode && valid) {
+                    float aq[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (acc_mode == 2) Quad<T>::load(acc + base + c, aq);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) aq[j] += (float)(T)o[j];
+                    Quad<T>::store(acc + base + c, aq);
+                }
                 if (nsum == 3) {
                     float oy[4];
 #pragma unroll
@@ -674,6 +684,9 @@ extern "C" int gm3d_add_ln_fwd(const void* x, const void* y, const float* ybias,
     return GM3D_OK;
 }
 
+extern "C" int gm3d_add_ln_bwd_acc(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, void* acc,
+                                   int acc_mode, int R, int C, int dtype, gm3d_stream_t stream);
 extern "C" int gm3d_add_ln_bwd(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
                                const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, int R, int C,
                                int dtype, gm3d_stream_t stream);
@@ -686,8 +699,17 @@ extern "C" int gm3d_ln_plain_bwd(const void* dh, const void* x, const float* mea
 extern "C" int gm3d_add_ln_bwd(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
                                const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, int R, int C,
                                int dtype, gm3d_stream_t stream) {
+    return gm3d_add_ln_bwd_acc(dh, gin, x, mean, rstd, gamma, rowscale, rows_per_sample, dx, dy, partial, nsum, nullptr, 0, R, C, dtype,
+                               stream);
+}
+
+extern "C" int gm3d_add_ln_bwd_acc(const void* dh, const void* gin, const void* x, const float* mean, const float* rstd, const float* gamma,
+                                   const float* rowscale, int rows_per_sample, void* dx, void* dy, float* partial, int nsum, void* acc,
+                                   int acc_mode, int R, int C, int dtype, gm3d_stream_t stream) {
     using namespace gm3d;
-    if (!x || !mean || !rstd || !gamma || !dx || !partial || R < 1 || (!dh && !gin)) return GM3D_EINVAL;
+    if (!dx || !partial || R < 1 || (!dh && !gin)) return GM3D_EINVAL;
+    if (dh && (!x || !mean || !rstd || !gamma)) return GM3D_EINVAL;           // dh == NULL: the sum-only backward reads none of them
+    if (acc_mode < 0 || acc_mode > 2 || (acc_mode && !acc)) return GM3D_EINVAL;
     if ((nsum != 2 && nsum != 3) || (rowscale && (!dy || rows_per_sample < 1))) return GM3D_EINVAL;
     if (C < 4 || C % 4 || C > 512) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
@@ -695,7 +717,7 @@ extern "C" int gm3d_add_ln_bwd(const void* dh, const void* gin, const void* x, c
     const int nq = (C + 127) / 128;
 #define GM3D_LNP_B(T_, NQ_) hipLaunchKernelGGL((ln_plain_bwd_kernel<T_, NQ_>), dim3(ln_grid(R)), dim3(256), 0, st, (const T_*)dh, (const T_*)x, \
                                                mean, rstd, gamma, (T_*)dx, partial, R, C, (const T_*)gin, rowscale, rows_per_sample,     \
-                                               (T_*)dy, nsum)
+                                               (T_*)dy, nsum, (T_*)acc, acc_mode)
     if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_B(bf16_t, 1); else if (nq == 2) GM3D_LNP_B(bf16_t, 2); else if (nq == 3) GM3D_LNP_B(bf16_t, 3); else GM3D_LNP_B(bf16_t, 4); }
     else { if (nq == 1) GM3D_LNP_B(float, 1); else if (nq == 2) GM3D_LNP_B(float, 2); else if (nq == 3) GM3D_LNP_B(float, 3); else GM3D_LNP_B(float, 4); }
 #undef GM3D_LNP_B

@@ -287,9 +287,9 @@ def mm(x, w, bias=None, out=None):
 
 
 def transposed(w):
-    """w (N,K) bf16 contiguous -> (K,N) contiguous, one launch of our transpose kernel (N, K % 64 == 0), else torch."""
+    """w (N,K) bf16 contiguous -> (K,N) contiguous, one launch of our transpose kernel (N, K % 8 == 0), else torch."""
     N, K = w.shape
-    if w.dtype == torch.bfloat16 and w.is_contiguous() and N % 64 == 0 and K % 64 == 0 and w.is_cuda:
+    if w.dtype == torch.bfloat16 and w.is_contiguous() and N % 8 == 0 and K % 8 == 0 and w.is_cuda and w.data_ptr() % 16 == 0:
         out = torch.empty(K, N, dtype=w.dtype, device=w.device)
         _launch("gm3d_transpose_bf16_batched", {"batch": 1, "rows": N, "cols": K}, lib.gm3d_transpose_bf16_batched, _ptr(w), _ptr(out),
                 1, N, K, N * K, _stream())
@@ -514,8 +514,8 @@ def stacked_transposes(groups):
         w0 = ws[0]
         n = len(ws)
         step = (ws[1].data_ptr() - w0.data_ptr()) if n > 1 else w0.numel() * w0.element_size()
-        regular = (w0.dtype == torch.bfloat16 and w0.is_cuda and w0.dim() == 2 and w0.shape[0] % 64 == 0 and w0.shape[1] % 64 == 0
-                   and step > 0 and step % w0.element_size() == 0 and step // w0.element_size() >= w0.numel()
+        regular = (w0.dtype == torch.bfloat16 and w0.is_cuda and w0.dim() == 2 and w0.shape[0] % 8 == 0 and w0.shape[1] % 8 == 0
+                   and w0.data_ptr() % 16 == 0 and step % 16 == 0 and step > 0 and step % w0.element_size() == 0 and step // w0.element_size() >= w0.numel()
                    and all(w.shape == w0.shape and w.is_contiguous() and w.data_ptr() - w0.data_ptr() == i * step for i, w in enumerate(ws)))
         ok = ok and regular
         metas.append((w0, n, step // w0.element_size()))
@@ -540,7 +540,8 @@ def stacked_transpose(ws):
         regular = step > 0 and step % w0.element_size() == 0 and all(
             w.shape == w0.shape and w.is_contiguous() and w.untyped_storage().data_ptr() == w0.untyped_storage().data_ptr()
             and w.data_ptr() - w0.data_ptr() == i * step for i, w in enumerate(ws))
-        if regular and w0.shape[0] % 64 == 0 and w0.shape[1] % 64 == 0 and w0.dtype == torch.bfloat16:
+        if (regular and w0.shape[0] % 8 == 0 and w0.shape[1] % 8 == 0 and w0.dtype == torch.bfloat16 and w0.data_ptr() % 16 == 0
+                and step % 16 == 0):
             N, K = w0.shape
             out = torch.empty(n, K, N, dtype=w0.dtype, device=w0.device)
             _launch("gm3d_transpose_bf16_batched", {"batch": n, "rows": N, "cols": K}, lib.gm3d_transpose_bf16_batched, _ptr(w0),

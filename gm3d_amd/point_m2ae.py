@@ -45,6 +45,11 @@ POOL_TAPS = None          # tests set this to a list: every max-pool of a grad-e
 #                           torch.amax's backward shares the gradient; the discrete decisions a gradient comparison has to share
 #                           (tests/test_gpu_m2ae.py)
 FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
+STACK_NODE = True         # a block stack as ONE autograd node (masked_stack.MaskedStackFn): the weight gradients of all its blocks in one
+#                           launch, one column-sum finish per kind, one transposing launch; FUSED_BLOCKS' per-op nodes are the cross-check
+VISIBLE_FIRST = True      # student pass: every level's stack runs on the visible tokens moved to the front of the cloud, cut to the
+#                           static bound the mask generator implies (12 of 64 -> 16, 96 of 256, all 512): the attention kernels skip the
+#                           filler tiles, levels 1-2 shrink to 3/8 and 1/4 of their rows.  Same results for visible tokens.
 
 
 def radius_mask(center, radius):
@@ -215,6 +220,10 @@ class BlockStack(nn.Module):
         self.blocks = nn.ModuleList([MaskedBlock(dim, num_heads, dpr[i]) for i in range(depth)])
 
     def forward(self, x, pos, bits=None):
+        if STACK_NODE and FUSED_BLOCKS and x.is_cuda:
+            from . import heads, masked_stack
+            if masked_stack.supported(x, self.blocks):
+                return masked_stack.run_stack(self.blocks, x, pos, bits, self.training, heads._adt())
         if FUSED_BLOCKS and x.is_cuda:
             from . import heads
             if heads.layer_norm_supported(x, x.shape[-1]) and x.shape[-1] % 8 == 0:
@@ -331,9 +340,23 @@ class PointM2AE(nn.Module):
         self.loss_func = ops.ChamferDistanceL2()
 
     # ------------------------------------------------------------------ forward
-    def encode(self, neighborhoods, centers, idxs, masks):
-        """-> per level: encoder outputs for every token position (only the visible ones are meaningful)."""
+    def _compact_bounds(self, vis_count):
+        """static row counts of the visible-first order per level, from the number of visible COARSEST tokens per cloud (None:
+        unknown -> every level keeps all its rows and is only re-ordered)."""
+        G, k = self.cfg["num_groups"], self.cfg["group_sizes"]
+        if vis_count is None:
+            return list(G)
+        up = lambda n, m: (n + m - 1) // m * m
+        b2 = min(G[2], up(vis_count, 16))
+        b1 = min(G[1], up(vis_count * k[2], 32))
+        b0 = min(G[0], up(vis_count * k[2] * k[1], 32))
+        return [b0, b1, b2]
+
+    def encode(self, neighborhoods, centers, idxs, masks, vis_count=None, compact=False):
+        """-> per level: encoder outputs for every token position (only the visible ones are meaningful).
+        compact: run each level's stack in the visible-first order (masked_stack.partition_visible)."""
         outs, prev = [], None
+        bounds = self._compact_bounds(vis_count) if compact else None
         for i in range(3):
             if i == 0:
                 from . import heads
@@ -352,6 +375,18 @@ class PointM2AE(nn.Module):
                 B, G, k = idxs[i].shape
                 from . import heads
                 tok = self.token_embed[i](heads.take_rows(prev, idxs[i].reshape(B, G * k)).view(B, G, k, -1))
+            if compact:
+                from . import masked_stack as S
+                with torch.no_grad():
+                    part = S.partition_visible(masks[i], bounds[i])
+                    cen_c = S.select_rows(centers[i], part["perm_c"])
+                    bits = ops.radius_mask_bits(cen_c, part["vis_c"], self.local_radius[i])
+                tok_c = S.CompactFn.apply(tok, part)
+                pos = _pos(self.encoder_pos_embeds[i], cen_c)
+                y_c = self.encoder_blocks[i](tok_c, pos.to(tok_c.dtype), bits)
+                prev = S.MergeFn.apply(y_c, tok, part)            # a masked token hands on its un-encoded embedding
+                outs.append(prev)
+                continue
             vis = ~masks[i]
             with torch.no_grad():       # == pack_mask(~(vis_i & vis_j) | radius_mask(centres)), one launch
                 bits = ops.radius_mask_bits(centers[i], vis, self.local_radius[i])
@@ -361,15 +396,18 @@ class PointM2AE(nn.Module):
             prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
         return outs
 
-    def forward(self, pts, mask=None, group=None, noaug=False):
+    def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None):
         """pts (B,N,3) f32; mask (B,64) bool over the COARSEST tokens (True = masked; None: nothing masked).
+        vis_count: the number of visible coarsest tokens of EVERY cloud when the caller knows it (generate_mask_ids keeps exactly
+        len_keep): a static bound for the visible-first order; a wrong bound sets masked_stack.overflow_flag.
         -> dict: rec (B,256,k1,3) reconstructed level-1 patches, loss_pred (B,64), masks (per level), group, features."""
         neighborhoods, centers, idxs = group if group is not None else self.group_divider(pts)
         B = centers[0].shape[0]
+        compact = VISIBLE_FIRST and STACK_NODE and FUSED_BLOCKS and mask is not None and centers[0].is_cuda
         if mask is None:
             mask = torch.zeros(B, self.num_group, dtype=torch.bool, device=centers[0].device)
         masks = back_project(mask, idxs)
-        enc = self.encode(neighborhoods, centers, idxs, masks)
+        enc = self.encode(neighborhoods, centers, idxs, masks, vis_count=vis_count, compact=compact)
         vis2, vis1 = ~masks[2], ~masks[1]
         x2 = self.encoder_norms[2](enc[2])
         if noaug:
@@ -431,7 +469,7 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
         mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
                                                       total_epoch=total_epoch, noise=mask_noise)
         masked = mask.to(torch.bool)
-    out = model(pts, mask=masked, group=group)
+    out = model(pts, mask=masked, group=group, vis_count=vis_ids.shape[1])
     lo = raw.forward_loss(out["rec"], group[0], group[2], out["masks"])
     pred = M.take(out["loss_pred"].float(), mask_ids)
     target = M.take(lo["matrix"].detach().float(), mask_ids)

@@ -159,6 +159,12 @@ int gm3d_add_ln_fwd(const void *x, const void *y, const float *ybias, const floa
 int gm3d_add_ln_bwd(const void *dh, const void *gin, const void *x, const float *mean, const float *rstd, const float *gamma,
                     const float *rowscale, int rows_per_sample, void *dx, void *dy, float *partial, int nsum, int R, int C, int dtype,
                     gm3d_stream_t stream);
+/* ... with a running sum over the sites that share an addend (the positional embedding re-added in front of every block of a
+ * stack): acc (R,C) `dtype`, acc_mode 0 none / 1 acc = dx / 2 acc += dx.  dh == NULL (no LayerNorm behind the sum): x, mean, rstd,
+ * gamma are not read and may be NULL. */
+int gm3d_add_ln_bwd_acc(const void *dh, const void *gin, const void *x, const float *mean, const float *rstd, const float *gamma,
+                        const float *rowscale, int rows_per_sample, void *dx, void *dy, float *partial, int nsum, void *acc,
+                        int acc_mode, int R, int C, int dtype, gm3d_stream_t stream);
 
 /* ---- Row-wise fused passes around the transformer-block GEMMs (gm3d_amd/csrc/rowops.hip) ------------
  * Together they restate timm-0.4.5 Block.forward (in-tree twin Point-MAE_SA3D/models/Point_MAE.py:128-146)
@@ -476,7 +482,8 @@ int gm3d_gemm_tn_bf16_dma_gelu(const void *A, const void *W, const float *bias, 
 int gm3d_gemm_tn_bf16_dma_gelu_bwd(const void *dO, const void *Wt, const void *F, const float *bias, void *dF, float *colpart, int M,
                                    int N, int K, int lda, int ldw, int ldf, int lddf, int bm, gm3d_stream_t stream);
 /* dst (batch, cols, rows) = transposes of `batch` row-major (rows, cols) bf16 matrices that start src_batch_stride elements apart
- * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 64. */
+ * (the per-block weights of one kind inside the optimizer's flat bf16 shadow).  rows, cols multiples of 8 (64 x 64 tiles, ragged edges
+ * guarded per 8-element chunk: the hierarchical model's 96 / 288-wide weights). */
 int gm3d_transpose_bf16_batched(const void *src, void *dst, int batch, int rows, int cols, long long src_batch_stride,
                                 gm3d_stream_t stream);
 /* `count` (<= 8) of those in ONE launch (the four transposed weight shadows a block stack's backward reads). */
@@ -544,6 +551,19 @@ int gm3d_gather_rows_bwd(const void *dy, const int *off, const int *list, void *
  * not visible (vis (B,G) bytes, NULL = all visible) or their centres (B,G,3) are >= radius apart (radius <= 0: no radius test). */
 int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float radius, int B, int G, unsigned *bits,
                           gm3d_stream_t stream);
+/* Visible-first token order of one masked level (the student's pass: multi-scale masking at ratio 0.8,
+ * Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99; gm3d_amd/point_m2ae.py).  masked (B,T) bytes (non-zero = masked), T <= 1024,
+ * 1 <= Tc <= T (a static bound on the visible count, or T):  perm_c (B,Tc) int32 = token at compact slot j (visible tokens in
+ * ascending order, then masked ones as filler); perm_v (B,Tc) = the same with -1 in filler slots; inv_v (B,T) = slot of token t
+ * if visible and below Tc, else -1; inv_m (B,T) = t if token t is masked, else -1; vis_c (B,Tc) bytes = 1 in slots holding a
+ * visible token; *overflow set to 1 if a cloud has
+ * more than Tc visible tokens (the caller's bound was wrong; never cleared here). */
+int gm3d_partition_visible(const unsigned char *masked, int B, int T, int Tc, int *perm_c, int *perm_v, int *inv_v, int *inv_m,
+                           unsigned char *vis_c, int *overflow, gm3d_stream_t stream);
+/* out (B,T,C) row by row: idx[b][t] >= 0 -> a[b][idx[b][t]] (a is (B,Ta,C)), else alt[b][t] (alt (B,T,C)) or zeros (alt NULL).
+ * elem_bytes 2 or 4.  Gather into / scatter out of the compact order above, forward and backward (indices without repeats). */
+int gm3d_select_rows(const void *a, const int *idx, const void *alt, void *out, int B, int Ta, int T, int C, int elem_bytes,
+                     gm3d_stream_t stream);
 int gm3d_attention_masked_fwd(const void *qkv, const unsigned *mask, void *out, float *lse, int B, int T, int H, int HD, float scale,
                               int dtype, gm3d_stream_t stream);
 int gm3d_attention_masked_bwd(const void *qkv, const unsigned *mask, const void *out, const void *dout, const float *lse, void *dqkv,

@@ -1,0 +1,173 @@
+"""-m gpu: gm3d_amd/masked_stack.py -- the Point-M2AE block stack as one autograd node, and the visible-first token order.
+
+ * MaskedStackFn against the per-op nodes it replaces (point_m2ae.BlockStack._forward_fused: the same kernels launched one
+   autograd node at a time): outputs EQUAL, gradients within the weight-gradient kernels' summation-order band;
+ * gm3d_partition_visible / gm3d_select_rows against a torch restatement (stable partition, gather, merge), incl. the overflow flag;
+ * the student pass of the whole model in the visible-first order against the in-place order: same reconstruction, scores, losses
+   and gradients (fp32: row-local layers are unchanged and the fp32 attention visits the allowed keys in the same order).
+The model itself has no reference source (Point-M2AE_SA3D/README.md:1): "parity unpinned", see tests/test_gpu_m2ae.py."""
+from contextlib import nullcontext
+
+import pytest
+import torch
+
+from tests import clouds
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max()) / max(float(b.double().abs().max()), 1e-12)
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+@pytest.mark.parametrize("shape", [(4, 256, 192, 0.64), (8, 512, 96, 0.32), (8, 64, 384, 0.0)])
+def test_stack_node_equals_per_op_nodes(bf16, shape):
+    from gm3d_amd import models_mae_learn_loss as MM
+    from gm3d_amd import ops
+    from gm3d_amd import point_m2ae as P
+    torch.manual_seed(0)
+    B, T, C, radius = shape
+    stack = P.BlockStack(C, 3, 6, [0.0, 0.05, 0.1]).cuda().train()
+    x = torch.randn(B, T, C, device="cuda")
+    pos = torch.randn(B, T, C, device="cuda") * 0.3
+    cen = clouds.pc_norm(torch.randn(B, T, 3)).cuda()
+    vis = torch.rand(B, T, device="cuda") < 0.7
+    bits = ops.radius_mask_bits(cen, vis, radius) if radius > 0 else None
+    draws = [(torch.rand(B, device="cuda") > 0.2).float() / 0.8 for _ in range(6)]
+    res = {}
+    was, was_dp = P.STACK_NODE, MM.drop_path_scale
+    try:
+        for node in (True, False):
+            P.STACK_NODE = node
+            it = iter(draws)
+            MM.drop_path_scale = lambda B_, p, training, device: next(it) if p > 0 else None
+            xi, pi = x.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+            for p_ in stack.parameters():
+                p_.grad = None
+            with (torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()):
+                out = stack(xi.bfloat16() if bf16 else xi, pi.bfloat16() if bf16 else pi, bits)
+            keep = vis.unsqueeze(-1).float() if bits is not None else torch.ones(B, T, 1, device="cuda")
+            (out.float() * keep * torch.linspace(0.5, 1.5, C, device="cuda")).sum().backward()
+            res[node] = (out.detach().float() * keep, xi.grad.clone(), pi.grad.clone(),
+                         {k: v.grad.detach().clone() for k, v in stack.named_parameters()})
+    finally:
+        P.STACK_NODE, MM.drop_path_scale = was, was_dp
+    assert torch.equal(res[True][0], res[False][0])              # the same forward kernels in the same order
+    tol = 2e-2 if bf16 else 2e-5
+    assert _rel(res[True][1], res[False][1]) <= tol and _rel(res[True][2], res[False][2]) <= tol
+    for k, v in res[False][3].items():
+        assert _rel(res[True][3][k], v) <= (2e-2 if bf16 else 2e-5), k
+
+
+def test_partition_and_select_kernels():
+    from gm3d_amd import masked_stack as S
+    g = torch.Generator().manual_seed(3)
+    flag = S.overflow_flag(torch.device("cuda"))
+    for B, T, Tc, p in ((5, 512, 512, 0.5), (7, 256, 96, 0.8), (3, 64, 16, 0.85), (2, 77, 77, 0.3), (4, 300, 128, 0.7)):
+        masked = torch.rand(B, T, generator=g) < p
+        # keep every cloud within the bound for this part of the test
+        for b in range(B):
+            v = (~masked[b]).nonzero().flatten()
+            if len(v) > Tc:
+                masked[b, v[Tc:]] = True
+        flag.zero_()
+        part = S.partition_visible(masked.cuda(), Tc)
+        assert int(flag) == 0
+        for b in range(B):
+            v = (~masked[b]).nonzero().flatten()
+            m = masked[b].nonzero().flatten()
+            order = torch.cat([v, m])[:Tc]
+            assert torch.equal(part["perm_c"][b].cpu().long(), order)
+            want_v = order.clone()
+            want_v[len(v):] = -1
+            assert torch.equal(part["perm_v"][b].cpu().long(), want_v)
+            inv = torch.full((T,), -1, dtype=torch.long)
+            inv[v] = torch.arange(len(v))
+            assert torch.equal(part["inv_v"][b].cpu().long(), inv)
+            assert torch.equal(part["inv_m"][b].cpu().long(), torch.where(masked[b], torch.arange(T), torch.tensor(-1)))
+            assert torch.equal(part["vis_c"][b].cpu().bool(), torch.arange(Tc) < len(v))
+        for dt, C in ((torch.bfloat16, 96), (torch.float32, 3), (torch.float32, 192), (torch.bfloat16, 3)):
+            x = torch.randn(B, T, C, generator=g).to(dt).cuda()
+            xc = S.select_rows(x, part["perm_c"])
+            assert torch.equal(xc, torch.gather(x, 1, part["perm_c"].long().unsqueeze(-1).expand(-1, -1, C)))
+            tok = torch.randn(B, T, C, generator=g).to(dt).cuda()
+            merged = S.select_rows(xc, part["inv_v"], tok)
+            want = torch.where(masked.cuda().unsqueeze(-1), tok, x)
+            assert torch.equal(merged, want)
+            zeros = S.select_rows(xc, part["inv_v"])
+            assert torch.equal(zeros, torch.where(masked.cuda().unsqueeze(-1), torch.zeros_like(x), x))
+    # a bound that is too small is reported
+    flag.zero_()
+    S.partition_visible(torch.zeros(2, 64, dtype=torch.bool, device="cuda"), 16)
+    assert int(flag) == 1
+    flag.zero_()
+
+
+def test_compact_and_merge_gradients():
+    from gm3d_amd import masked_stack as S
+    torch.manual_seed(1)
+    B, T, Tc, C = 4, 256, 96, 192
+    masked = torch.rand(B, T, device="cuda") < 0.75
+    part = S.partition_visible(masked, Tc)
+    x = torch.randn(B, T, C, device="cuda", requires_grad=True)
+    tok = torch.randn(B, T, C, device="cuda", requires_grad=True)
+    w = torch.randn(B, T, C, device="cuda")
+    yc = S.CompactFn.apply(x, part) * 2.0
+    out = S.MergeFn.apply(yc, tok, part)
+    (out * w).sum().backward()
+    vis = (~masked).unsqueeze(-1)
+    assert torch.equal(out.detach(), torch.where(vis, 2.0 * x.detach(), tok.detach()))
+    assert torch.equal(x.grad, torch.where(vis, 2.0 * w, torch.zeros_like(w)))
+    assert torch.equal(tok.grad, torch.where(vis, torch.zeros_like(w), w))
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_visible_first_order_equals_in_place_order(bf16):
+    """The student pass of the whole model (multi-scale masks from a 12-of-64 coarse mask) with the stacks in the visible-first
+    order (bounds 512 / 96 / 16 rows) against the in-place order."""
+    from gm3d_amd import masked_stack as S
+    from gm3d_amd import point_m2ae as P
+    from gm3d_amd import models_mae_learn_loss as MM
+    torch.manual_seed(5)
+    B = 4
+    model = P.PointM2AE().cuda().train()
+    for mod in model.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    pts = clouds.gaussian(B, 2048, seed=11).cuda()
+    score = torch.rand(B, 64, device="cuda")
+    mask, vis_ids, mask_ids = MM.generate_mask_ids(score, mask_ratio=0.8, guide=True, epoch=10, total_epoch=300)
+    masked = mask.bool()
+    assert vis_ids.shape[1] == 12
+    with torch.no_grad():
+        group = model.group_divider(pts)
+    flag = S.overflow_flag(pts.device)
+    flag.zero_()
+    res = {}
+    was = P.VISIBLE_FIRST
+    try:
+        for vf in (True, False):
+            P.VISIBLE_FIRST = vf
+            model.zero_grad(set_to_none=True)
+            # BatchNorm running statistics move with every forward: same start for both runs
+            sd = {k: v.clone() for k, v in model.state_dict().items()}
+            with (torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()):
+                out = model(pts, mask=masked, group=group, vis_count=12)
+                lo = model.forward_loss(out["rec"], group[0], group[2], out["masks"])
+            (lo["Chamfer_mean"] + out["loss_pred"].float().mean()).backward()
+            res[vf] = (out["rec"].detach().float(), out["loss_pred"].detach().float(), lo["Chamfer_mean"].detach().float(),
+                       {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None})
+            model.load_state_dict(sd)
+    finally:
+        P.VISIBLE_FIRST = was
+    assert int(flag) == 0
+    tol = 3e-2 if bf16 else 2e-5
+    assert _rel(res[True][0], res[False][0]) <= tol
+    assert _rel(res[True][1], res[False][1]) <= tol
+    assert _rel(res[True][2], res[False][2]) <= tol
+    assert set(res[True][3]) == set(res[False][3])
+    gscale = max(float(v.abs().max()) for v in res[False][3].values())
+    for k, v in res[False][3].items():
+        err = float((res[True][3][k] - v).abs().max()) / max(float(v.abs().max()), 1e-3 * gscale)
+        assert err <= (6e-2 if bf16 else 1e-4), (k, err)
