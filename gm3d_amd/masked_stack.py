@@ -224,6 +224,9 @@ _overflow = {}
 def overflow_flag(device):
     """(1,) int32 on `device`: set by gm3d_partition_visible when a cloud had more visible tokens than the caller's static bound
     (the compacted pass then dropped tokens).  The engine / tests read it; it is never cleared by the kernels."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     key = str(device)
     if key not in _overflow:
         _overflow[key] = torch.zeros(1, dtype=torch.int32, device=device)
