@@ -124,6 +124,9 @@ SIGNATURES = {
     "gm3d_add_ln_bwd_acc": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "gm3d_partition_visible": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "gm3d_select_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gm3d_back_project": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "gm3d_interp3_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gather_rows_bwd_w": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gm3d_colsum_partial_w": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dmaw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

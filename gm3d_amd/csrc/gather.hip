@@ -213,3 +213,138 @@ extern "C" int gm3d_select_rows(const void* a, const int* idx, const void* alt, 
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
+
+// ===================================================================== token propagation (3-NN interpolation) of the hierarchical decoder
+// Up-block of Point-M2AE's H_Decoder (PointNet++ feature propagation; hyper-parameters Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:88-99,
+// gm3d_amd/point_m2ae.py TokenPropagation): every fine token takes the inverse-squared-distance weighted mean of its three nearest coarse
+// tokens, concatenated behind its own features:
+//   out[b][n][0:C1]      = fine[b][n][:]
+//   out[b][n][C1:C1+C2]  = (w[b][n][0] * coarse[b][idx[b][n][0]] + w[..][1] * coarse[..idx 1]) + w[..][2] * coarse[..idx 2]   (fp32, one rounding)
+// Backward of the interpolated half: gm3d_gather_inverse over idx (B, 3N) + gm3d_gather_rows_bwd_w (every coarse token sums its readers'
+// weighted gradients in ascending reader order: deterministic).
+namespace gm3d {
+
+template <class T>
+__global__ __launch_bounds__(256) void interp3_fwd_kernel(const T* __restrict__ coarse, const long long* __restrict__ idx,
+                                                          const float* __restrict__ w, const T* __restrict__ fine, T* __restrict__ out,
+                                                          int N, int S, int C1, int C2, long long total) {
+    const int cpr1 = C1 >> 3, cpr = (C1 + C2) >> 3;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long row = g / cpr;                    // b * N + n
+        const int ch = (int)(g - row * cpr);
+        float v[8];
+        if (ch < cpr1) {
+            V8<T>::load(fine + (size_t)row * C1 + ch * 8, v);
+        } else {
+            const int b = (int)(row / N), c = (ch - cpr1) * 8;
+            const long long* ip = idx + (size_t)row * 3;
+            const float* wp = w + (size_t)row * 3;
+            float a0[8], a1[8], a2[8];
+            V8<T>::load(coarse + ((size_t)b * S + (int)ip[0]) * C2 + c, a0);
+            V8<T>::load(coarse + ((size_t)b * S + (int)ip[1]) * C2 + c, a1);
+            V8<T>::load(coarse + ((size_t)b * S + (int)ip[2]) * C2 + c, a2);
+            const float w0 = wp[0], w1 = wp[1], w2 = wp[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (w0 * a0[e] + w1 * a1[e]) + w2 * a2[e];
+        }
+        V8<T>::store(out + (size_t)row * (C1 + C2) + ch * 8, v);
+    }
+}
+
+// dx (B, S, C) = sum over each source's list (ascending reference j) of w[b][j] * dy[b][j / rpr][col0 : col0 + C]; dy rows have pitch ldy
+template <class T>
+__global__ __launch_bounds__(256) void gather_rows_bwd_w_kernel(const T* __restrict__ dy, int ldy, int col0, int rpr,
+                                                                const float* __restrict__ w, const int* __restrict__ off,
+                                                                const int* __restrict__ list, T* __restrict__ dx, int J, int S, int C,
+                                                                long long total) {
+    const int cpr = C >> 3;
+    const int rows_b = J / rpr;                           // dy rows per batch entry
+    for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long long)gridDim.x * 256) {
+        const long long row = t / cpr;                    // b * S + s
+        const int c = (int)(t - row * cpr) * 8;
+        const int b = (int)(row / S), s = (int)(row - (long long)b * S);
+        const int* ob = off + (size_t)b * (S + 1);
+        const int lo = ob[s], hi = ob[s + 1];
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int i = lo; i < hi; ++i) {
+            const int j = list[(size_t)b * J + i];
+            const float wj = w[(size_t)b * J + j];
+            float v[8];
+            V8<T>::load(dy + ((size_t)b * rows_b + j / rpr) * ldy + col0 + c, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += wj * v[e];
+        }
+        V8<T>::store(dx + (size_t)row * C + c, acc);
+    }
+}
+
+// multi-scale masking, one level down: a group of level l-1 is visible iff at least one VISIBLE group of level l lists it as a member.
+// masked_c (B, Gc) bytes (non-zero = masked) of the coarser level, member (B, Gc, k) int64 into the finer level's Gf groups
+// -> masked_f (B, Gf) bytes.  One workgroup per cloud, flags in LDS.
+__global__ __launch_bounds__(256) void back_project_kernel(const unsigned char* __restrict__ masked_c, const long long* __restrict__ member,
+                                                           int Gc, int k, int Gf, unsigned char* __restrict__ masked_f) {
+    extern __shared__ int seen[];
+    const int b = blockIdx.x;
+    for (int g = threadIdx.x; g < Gf; g += 256) seen[g] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < Gc * k; i += 256)
+        if (masked_c[(size_t)b * Gc + i / k] == 0) seen[(int)member[(size_t)b * Gc * k + i]] = 1;      // benign race: every writer stores 1
+    __syncthreads();
+    for (int g = threadIdx.x; g < Gf; g += 256) masked_f[(size_t)b * Gf + g] = seen[g] ? 0 : 1;
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_interp3_fwd(const void* coarse, const long long* idx, const float* w, const void* fine, void* out, int B, int N, int S,
+                                int C1, int C2, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!coarse || !idx || !w || !out || B < 0 || N < 1 || S < 1 || C1 < 0 || C2 < 8 || (C1 > 0 && !fine)) return GM3D_EINVAL;
+    if (C1 % 8 || C2 % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    const long long total = (long long)B * N * ((C1 + C2) / 8);
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(interp3_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)coarse, idx, w, (const bf16_t*)fine,
+                           (bf16_t*)out, N, S, C1, C2, total);
+    else
+        hipLaunchKernelGGL(interp3_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)coarse, idx, w, (const float*)fine,
+                           (float*)out, N, S, C1, C2, total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_gather_rows_bwd_w(const void* dy, int ldy, int col0, int refs_per_row, const float* w, const int* off, const int* list,
+                                      void* dx, int B, int J, int S, int C, int dtype, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!dy || !w || !off || !list || !dx || B < 0 || J < 1 || S < 1 || C < 8 || refs_per_row < 1 || J % refs_per_row || col0 < 0 ||
+        ldy < col0 + C)
+        return GM3D_EINVAL;
+    if (C % 8 || ldy % 8 || col0 % 8) return GM3D_EUNSUPPORTED;
+    if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    const long long total = (long long)B * S * (C / 8);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GM3D_BF16)
+        hipLaunchKernelGGL(gather_rows_bwd_w_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, ldy, col0, refs_per_row, w, off,
+                           list, (bf16_t*)dx, J, S, C, total);
+    else
+        hipLaunchKernelGGL(gather_rows_bwd_w_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, ldy, col0, refs_per_row, w, off,
+                           list, (float*)dx, J, S, C, total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_back_project(const unsigned char* masked_c, const long long* member, int B, int Gc, int k, int Gf,
+                                 unsigned char* masked_f, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!masked_c || !member || !masked_f || B < 0 || Gc < 1 || k < 1 || Gf < 1) return GM3D_EINVAL;
+    if (Gf > 8192) return GM3D_EUNSUPPORTED;
+    if (B == 0) return GM3D_OK;
+    hipLaunchKernelGGL(back_project_kernel, dim3(B), dim3(256), (size_t)Gf * sizeof(int), (hipStream_t)stream, masked_c, member, Gc, k, Gf,
+                       masked_f);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

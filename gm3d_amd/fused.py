@@ -79,6 +79,12 @@ class _WeightCache:
         hit = self._pinned.get(w.data_ptr())
         if hit is not None and hit[1]() is w and hit[0].dtype == dtype:
             return hit[0]
+        base = w._base
+        if base is not None and base.dtype == w.dtype:
+            # a view of a pinned parameter (the [global | local] column halves of a mini-PointNet conv): the same view of its shadow
+            hit = self._pinned.get(base.data_ptr())
+            if hit is not None and hit[1]() is base and hit[0].dtype == dtype and hit[0].numel() == base.numel():
+                return torch.as_strided(hit[0], w.size(), w.stride(), hit[0].storage_offset() + w.storage_offset() - base.storage_offset())
         if torch.cuda.is_current_stream_capturing():
             return w.detach().to(dtype)
         key = (w.data_ptr(), dtype, tuple(w.shape))

@@ -215,6 +215,71 @@ class TakeRowsFn(torch.autograd.Function):
         return dx.to(ctx.xdt), None
 
 
+class GroupMaxFn(torch.autograd.Function):
+    """x (G,K,C) -> (G,C): max over the K members of a group (the pooling of a mini-PointNet token embed, P/:895,898
+    `torch.max(.., dim)[0]`) on csrc/embed.hip's group_max kernels: the winner is the FIRST maximising member (uint8 index), the
+    backward hands the gradient to that member only -- torch.max's convention, the one the level-0 embed (embed.EmbedFn) uses."""
+
+    @staticmethod
+    def forward(ctx, x):
+        G, K, C = x.shape
+        x = x.contiguous()
+        out = torch.empty(G, C, dtype=x.dtype, device=x.device)
+        arg = torch.empty(G, C, dtype=torch.uint8, device=x.device)
+        _launch("gm3d_group_max_fwd", {"G": G, "K": K, "C": C, "dtype": str(x.dtype)}, lib.gm3d_group_max_fwd, _ptr(x), None, _ptr(out),
+                _ptr(arg), G, K, C, _DT[x.dtype], _stream())
+        ctx.save_for_backward(arg)
+        ctx.dims = (G, K, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        G, K, C = ctx.dims
+        dout = dout.contiguous()
+        dx = torch.empty(G, K, C, dtype=dout.dtype, device=dout.device)
+        _launch("gm3d_group_max_bwd", {"G": G, "K": K, "C": C, "dtype": str(dout.dtype)}, lib.gm3d_group_max_bwd, _ptr(dout), _ptr(arg),
+                _ptr(dx), G, K, C, _DT[dout.dtype], _stream())
+        return dx
+
+
+def group_max_supported(x):
+    return x.is_cuda and x.dim() == 3 and x.dtype in _DT and x.shape[2] % 8 == 0 and 1 <= x.shape[1] <= 255 and x.shape[2] <= 1024
+
+
+class Interp3Fn(torch.autograd.Function):
+    """[fine | sum_j w_j * coarse[idx_j]] -> (B,N,C1+C2): the token propagation's 3-NN interpolation and concatenation as one launch
+    (csrc/gather.hip gm3d_interp3_fwd); backward: the fine half is a slice, the coarse tokens sum their readers' weighted gradients in
+    ascending reader order (gm3d_gather_inverse + gm3d_gather_rows_bwd_w: deterministic)."""
+
+    @staticmethod
+    def forward(ctx, fine, coarse, idx, w):
+        B, N, C1 = fine.shape
+        S, C2 = coarse.shape[1], coarse.shape[2]
+        fine, coarse = fine.contiguous(), coarse.to(fine.dtype).contiguous()
+        idx, w = idx.contiguous(), w.float().contiguous()
+        out = torch.empty(B, N, C1 + C2, dtype=fine.dtype, device=fine.device)
+        _launch("gm3d_interp3_fwd", {"B": B, "N": N, "C": C1 + C2, "dtype": str(fine.dtype)}, lib.gm3d_interp3_fwd, _ptr(coarse), _ptr(idx),
+                _ptr(w), _ptr(fine), _ptr(out), B, N, S, C1, C2, _DT[fine.dtype], _stream())
+        ctx.save_for_backward(idx, w)
+        ctx.dims = (B, N, S, C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, w = ctx.saved_tensors
+        B, N, S, C1, C2 = ctx.dims
+        dout = dout.contiguous()
+        J = 3 * N
+        off = torch.empty(B, S + 1, dtype=torch.int32, device=dout.device)
+        lst = torch.empty(B, J, dtype=torch.int32, device=dout.device)
+        _launch("gm3d_gather_inverse", {"B": B, "J": J, "S": S}, lib.gm3d_gather_inverse, _ptr(idx), B, J, S, _ptr(off), _ptr(lst), _stream())
+        dcoarse = torch.empty(B, S, C2, dtype=dout.dtype, device=dout.device)
+        _launch("gm3d_gather_rows_bwd", {"B": B, "J": J, "S": S, "C": C2, "dtype": str(dout.dtype)}, lib.gm3d_gather_rows_bwd_w, _ptr(dout),
+                C1 + C2, C1, 3, _ptr(w), _ptr(off), _ptr(lst), _ptr(dcoarse), B, J, S, C2, _DT[dout.dtype], _stream())
+        return dout[..., :C1], dcoarse, None, None
+
+
 def take_rows(x, ids):
     """x (B,S,C) gathered along dim 1 by ids (B,J) with a deterministic backward (GPU, C % 8 == 0); else models_mae_learn_loss.take."""
     if x.is_cuda and x.dim() == 3 and x.shape[-1] % 8 == 0 and ids.dtype == torch.int64 and x.shape[1] <= 4096 and ids.shape[1] <= 16384:

@@ -45,6 +45,7 @@ POOL_TAPS = None          # tests set this to a list: every max-pool of a grad-e
 #                           torch.amax's backward shares the gradient; the discrete decisions a gradient comparison has to share
 #                           (tests/test_gpu_m2ae.py)
 FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
+FUSED_PROPAGATION = True  # token propagation: 3-NN interpolation + concatenation as one launch (heads.Interp3Fn), deterministic backward
 STACK_NODE = True         # a block stack as ONE autograd node (masked_stack.MaskedStackFn): the weight gradients of all its blocks in one
 #                           launch, one column-sum finish per kind, one transposing launch; FUSED_BLOCKS' per-op nodes are the cross-check
 VISIBLE_FIRST = True      # student pass: every level's stack runs on the visible tokens moved to the front of the cloud, cut to the
@@ -65,8 +66,20 @@ def radius_mask(center, radius):
 
 def back_project(mask_coarse, idxs):
     """Multi-scale masking: mask_coarse (B,G_last) bool (True = masked) -> [mask_0 .. mask_last]; a finer group is visible iff at
-    least one visible group of the next coarser level contains it.  Static shapes (integer scatter-add, no host sync)."""
+    least one visible group of the next coarser level contains it.  Static shapes, no host sync: one launch per level on the GPU
+    (gm3d_back_project), an integer scatter-add elsewhere."""
     masks = [mask_coarse]
+    if mask_coarse.is_cuda and mask_coarse.dtype == torch.bool:
+        from ._capi import lib
+        for lvl in range(len(idxs) - 1, 0, -1):
+            idx = idxs[lvl].contiguous()
+            B, Gc, k = idx.shape
+            Gf = idxs[lvl - 1].shape[1]
+            out = torch.empty(B, Gf, dtype=torch.bool, device=idx.device)
+            ops._launch("gm3d_back_project", {"B": B, "Gc": Gc, "Gf": Gf}, lib.gm3d_back_project, ops._ptr(masks[0].contiguous()),
+                        ops._ptr(idx), B, Gc, k, Gf, ops._ptr(out), ops._stream())
+            masks.insert(0, out)
+        return masks
     for lvl in range(len(idxs) - 1, 0, -1):
         idx = idxs[lvl]                                               # (B,G_l,k_l) members among the level l-1 groups
         B, G_prev = idx.shape[0], idxs[lvl - 1].shape[1]
@@ -158,11 +171,12 @@ class TokenEmbed(nn.Module):
         a1 = heads.bn_bcast_act(_linear(x, c0.weight, None), t0, bn0, k)
         f = _linear(a1, c1.weight, c1.bias)                                            # (rows, b)
         b_ = f.shape[-1]
-        fg = f.view(B * G, k, b_).amax(dim=1)                                          # (B*G, b)
+        pool = (lambda t: heads.GroupMaxFn.apply(t)) if heads.group_max_supported(f.view(B * G, k, b_)) else (lambda t: t.amax(dim=1))
+        fg = pool(f.view(B * G, k, b_))                                                # (B*G, b)
         W3 = c2.weight.squeeze(-1)                                                     # (mid, 2b): [global | local] columns
         a2 = heads.bn_bcast_act(_linear(f, W3[:, b_:], None), _linear(fg, W3[:, :b_], c2.bias), bn1, k)
         z = _linear(a2, c3.weight, c3.bias)
-        return z.view(B * G, k, self.out_c).amax(dim=1).view(B, G, self.out_c)
+        return pool(z.view(B * G, k, self.out_c)).view(B, G, self.out_c)
 
     def forward(self, groups):
         B, G, k, C = groups.shape
@@ -278,9 +292,12 @@ class TokenPropagation(nn.Module):
             w = 1.0 / (dist * dist + 1e-8)
             w = w / w.sum(dim=-1, keepdim=True)
         from . import heads
-        near = heads.take_rows(tok_coarse, idx.reshape(B, N * 3)).view(B, N, 3, -1)     # (deterministic backward: a coarse token has many readers)
-        interp = (near * w.unsqueeze(-1).to(near.dtype)).sum(dim=2)
-        y = torch.cat([tok_fine, interp.to(tok_fine.dtype)], dim=-1).reshape(B * N, -1)
+        if FUSED_PROPAGATION and tok_fine.is_cuda and tok_fine.dtype in ops._DT and tok_fine.shape[-1] % 8 == 0 and tok_coarse.shape[-1] % 8 == 0:
+            y = heads.Interp3Fn.apply(tok_fine, tok_coarse, idx, w).reshape(B * N, -1)       # interpolation + concatenation: one launch
+        else:
+            near = heads.take_rows(tok_coarse, idx.reshape(B, N * 3)).view(B, N, 3, -1)     # (deterministic backward: a coarse token has many readers)
+            interp = (near * w.unsqueeze(-1).to(near.dtype)).sum(dim=2)
+            y = torch.cat([tok_fine, interp.to(tok_fine.dtype)], dim=-1).reshape(B * N, -1)
         for conv, bn in zip(self.mlp_convs, self.mlp_bns):
             y = _lin(y, conv, bn, True)
         return y.view(B, N, -1)

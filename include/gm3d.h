@@ -560,6 +560,19 @@ int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float r
  * more than Tc visible tokens (the caller's bound was wrong; never cleared here). */
 int gm3d_partition_visible(const unsigned char *masked, int B, int T, int Tc, int *perm_c, int *perm_v, int *inv_v, int *inv_m,
                            unsigned char *vis_c, int *overflow, gm3d_stream_t stream);
+/* Multi-scale masking one level down (gm3d_amd/point_m2ae.py back_project): masked_f (B,Gf) bytes = 1 unless some VISIBLE group of the
+ * coarser level (masked_c (B,Gc) bytes, 0 = visible) lists the finer group among its k members (member (B,Gc,k) int64).  Gf <= 8192. */
+int gm3d_back_project(const unsigned char *masked_c, const long long *member, int B, int Gc, int k, int Gf, unsigned char *masked_f,
+                      gm3d_stream_t stream);
+/* Token propagation of the hierarchical decoder (3-NN inverse-squared-distance interpolation, PointNet++ style; configuration
+ * Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:88-99): out (B,N,C1+C2) = [fine (B,N,C1) | sum_j w[b][n][j] * coarse[b][idx[b][n][j]]],
+ * coarse (B,S,C2), idx (B,N,3) int64, w (B,N,3) f32; C1, C2 % 8 == 0 (C1 = 0: no fine part).  Backward of the interpolated half:
+ * gm3d_gather_inverse over idx viewed as (B,3N), then gm3d_gather_rows_bwd_w: dx (B,S,C) = sum over each source's list, in list order,
+ * of w[b][j] * dy[b][j / refs_per_row][col0 : col0 + C] (dy rows of pitch ldy). */
+int gm3d_interp3_fwd(const void *coarse, const long long *idx, const float *w, const void *fine, void *out, int B, int N, int S, int C1,
+                     int C2, int dtype, gm3d_stream_t stream);
+int gm3d_gather_rows_bwd_w(const void *dy, int ldy, int col0, int refs_per_row, const float *w, const int *off, const int *list, void *dx,
+                           int B, int J, int S, int C, int dtype, gm3d_stream_t stream);
 /* out (B,T,C) row by row: idx[b][t] >= 0 -> a[b][idx[b][t]] (a is (B,Ta,C)), else alt[b][t] (alt (B,T,C)) or zeros (alt NULL).
  * elem_bytes 2 or 4.  Gather into / scatter out of the compact order above, forward and backward (indices without repeats). */
 int gm3d_select_rows(const void *a, const int *idx, const void *alt, void *out, int B, int Ta, int T, int C, int elem_bytes,

@@ -174,3 +174,50 @@ def test_visible_first_order_equals_in_place_order(bf16):
         # (floor: a bias in front of a BatchNorm has an exactly zero gradient -- both sides hold rounding residue only)
         err = float((res[True][3][k] - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gscale)
         assert err <= (1e-1 if bf16 else 1e-4), (k, err)
+
+
+def test_back_project_kernel_equals_scatter_form():
+    from gm3d_amd import point_m2ae as P
+    g = torch.Generator().manual_seed(0)
+    B = 5
+    idxs = [torch.randint(0, 2048, (B, 512, 16), generator=g), torch.randint(0, 512, (B, 256, 8), generator=g),
+            torch.randint(0, 256, (B, 64, 8), generator=g)]
+    coarse = torch.rand(B, 64, generator=g) < 0.8
+    want = P.back_project(coarse, idxs)                       # CPU: the integer scatter-add form
+    got = P.back_project(coarse.cuda(), [i.cuda() for i in idxs])
+    assert len(got) == 3
+    for a, b in zip(got, want):
+        assert a.dtype == torch.bool and torch.equal(a.cpu(), b)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_interp3_and_group_max_nodes(dtype):
+    from gm3d_amd import heads
+    torch.manual_seed(2)
+    B, N, S, C1, C2 = 3, 256, 64, 192, 384
+    fine = torch.randn(B, N, C1, device="cuda").to(dtype).requires_grad_(True)
+    coarse = torch.randn(B, S, C2, device="cuda").to(dtype).requires_grad_(True)
+    idx = torch.randint(0, S, (B, N, 3), device="cuda")
+    w = torch.rand(B, N, 3, device="cuda")
+    w = w / w.sum(-1, keepdim=True)
+    out = heads.Interp3Fn.apply(fine, coarse, idx, w)
+    g = torch.randn_like(out.float())
+    (out.float() * g).sum().backward()
+    f64, c64 = fine.detach().double().requires_grad_(True), coarse.detach().double().requires_grad_(True)
+    near = torch.gather(c64, 1, idx.reshape(B, N * 3, 1).expand(-1, -1, C2)).view(B, N, 3, C2)
+    ref = torch.cat([f64, (near * w.double().unsqueeze(-1)).sum(2)], dim=-1)
+    (ref * g.double()).sum().backward()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    assert _rel(out.detach(), ref.detach()) <= tol
+    assert _rel(fine.grad, f64.grad) <= tol and _rel(coarse.grad, c64.grad) <= tol
+    # group max: first maximising member, gradient to that member
+    x = torch.randn(40, 8, 96, device="cuda").to(dtype)
+    x[3, 5] = x[3, 2]                                              # an exact tie: the earlier member wins
+    x.requires_grad_(True)
+    y = heads.GroupMaxFn.apply(x)
+    y.float().sum().backward()
+    vals, arg = x.detach().float().max(dim=1)
+    assert torch.equal(y.detach().float(), vals)
+    first = (x.detach().float() == vals.unsqueeze(1)).float().argmax(dim=1)
+    want = torch.zeros_like(x.detach().float()).scatter_(1, first.unsqueeze(1), 1.0)
+    assert torch.equal(x.grad.float(), want)
