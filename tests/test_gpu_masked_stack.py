@@ -170,10 +170,18 @@ def test_visible_first_order_equals_in_place_order(bf16):
     assert _rel(res[True][2], res[False][2]) <= tol
     assert set(res[True][3]) == set(res[False][3])
     gscale = max(float(v.abs().max()) for v in res[False][3].values())
+    if bf16:
+        # weights in front of a BatchNorm over 16k-1M rows have gradients that are small differences of large sums (tests/test_gpu_m2ae.py):
+        # in bf16 they carry tens of percent of noise in EITHER order, so the bar here is on the gradient as a whole
+        a = torch.cat([res[True][3][k].flatten().double() for k in sorted(res[False][3])])
+        b = torch.cat([res[False][3][k].flatten().double() for k in sorted(res[False][3])])
+        assert float(torch.dot(a, b) / (a.norm() * b.norm())) >= 0.98
+        assert abs(float(a.norm() / b.norm()) - 1.0) <= 0.05
+        return
     for k, v in res[False][3].items():
         # (floor: a bias in front of a BatchNorm has an exactly zero gradient -- both sides hold rounding residue only)
         err = float((res[True][3][k] - v).abs().max()) / max(float(v.abs().max()), 1e-2 * gscale)
-        assert err <= (1e-1 if bf16 else 1e-4), (k, err)
+        assert err <= 1e-4, (k, err)
 
 
 def test_back_project_kernel_equals_scatter_form():
