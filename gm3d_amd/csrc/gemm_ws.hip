@@ -74,7 +74,11 @@ template <int KT, int NW, int NL, int EPI, int TM>
 __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                      const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N,
                                                                      int lda, int ldw, int ldc, int tiles_n, bf16_t* __restrict__ P,
-                                                                     uint8_t* __restrict__ ARG, int ldp, int bias_after_pool, WsBn bn) {
+                                                                     uint8_t* __restrict__ ARG, int ldp, int bias_after_pool, WsBn bn,
+                                                                     int Kreal) {
+    // Kreal <= 64 KT: the true K (a multiple of 8) when it is not a multiple of the 64-column images (the hierarchical model's 96- and
+    // 288-wide products).  Columns past it are never read: the loader's pieces there re-read column 0 of the same row (finite wherever
+    // the row is), and the resident W fragments are zero from Kreal on, so those k contribute exactly 0.
     extern __shared__ __attribute__((aligned(16))) unsigned char wsm[];
     constexpr int BN = 32 * NW, NIMG = BN / 64 > 0 ? (BN + 63) / 64 : 1;
     constexpr int HALF = KT * 4096;                 // bytes of one [32][K] sub-tile: KT swizzled [32][64] images
@@ -110,7 +114,9 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 #ifdef GM3D_WS_PROBE_NO_LOAD
                 if (i < DEPTH)
 #endif
-                ws_glds16(A + (size_t)am * lda + 64 * kt + ((pslot ^ ws_f(row)) << 3), base + 1024 * p);
+                int col = 64 * kt + ((pslot ^ ws_f(row)) << 3);
+                col = col < Kreal ? col : 0;
+                ws_glds16(A + (size_t)am * lda + col, base + 1024 * p);
             }
         };
         for (int d = 0; d < DEPTH && d < nmine; ++d) issue(d);
@@ -133,7 +139,12 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
 #pragma unroll
         for (int kt = 0; kt < KT; ++kt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) wreg[kt][s] = *reinterpret_cast<const wbf16x8*>(wp + 64 * kt + 16 * s);
+            for (int s = 0; s < 4; ++s) {
+                if (64 * kt + 16 * s + 8 * hh < Kreal) wreg[kt][s] = *reinterpret_cast<const wbf16x8*>(wp + 64 * kt + 16 * s);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) wreg[kt][s][e] = (bf16_t)0.0f;
+            }
     }
     float bq[4][4];
 #pragma unroll
@@ -350,7 +361,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
     using namespace gm3d;
     if (!A || !W || (!C && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
     if (P && (!ARG || M % 32 || ldp % 8 || ldp < N || ((size_t)ARG & 7) || ((size_t)P & 15))) return GM3D_EINVAL;
-    if (K % 64 || K > 512 || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
+    if (K % 8 || K > 512 || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
     if (((size_t)A | (size_t)W | (size_t)C) & 15) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -365,7 +376,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>, lds)) return GM3D_ELAUNCH;                 \
         hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>), dim3(grid), dim3(64 * (NW + NL)), lds, st,          \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp, \
-                           bias_after_pool, bn);                                                                         \
+                           bias_after_pool, bn, K);                                                                      \
         GM3D_CHECK_LAUNCH();                                                                                             \
         return GM3D_OK;                                                                                                  \
     }
@@ -388,6 +399,13 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
     if (K == 256 && N == 128) GM3D_WS_LAUNCH(4, 4, 1, 0, 1)           // first_conv.3's input gradient
     if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 0, 1)
     if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 0, 1)
+    // level 0 of the hierarchical encoder (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99: 96-wide blocks over B * 512 = 65,536 token
+    // rows): qkv / proj / fc1 / fc2 and their input gradients -- ragged K (96, 288) through the Kreal path
+    if (K == 96 && N == 288) GM3D_WS_LAUNCH(2, 9, 1, 0, 1)           // qkv
+    if (K == 96 && N == 96) GM3D_WS_LAUNCH(2, 3, 1, 0, 1)            // proj, and its input gradient
+    if (K == 96 && N == 384) GM3D_WS_LAUNCH(2, 6, 1, 0, 1)           // fc1, fc2's input gradient (two column blocks of 192)
+    if (K == 384 && N == 96) GM3D_WS_LAUNCH(6, 3, 1, 0, 1)           // fc2, fc1's input gradient
+    if (K == 288 && N == 96) GM3D_WS_LAUNCH(5, 3, 1, 0, 1)           // qkv's input gradient
 #undef GM3D_WS_LAUNCH
     return GM3D_EUNSUPPORTED;
 }
@@ -439,5 +457,6 @@ extern "C" int gm3d_gemm_ws_stats_rows(int M, int N, int K) {
 extern "C" int gm3d_gemm_ws_supported(int N, int K, int pool) {
     if (pool) return (K == 128 && N == 256) || (K == 512 && N == 384);
     return (K == 256 && N == 512) || (K == 512 && N == 256) || (K == 384 && N == 512) || (K == 256 && N == 128) ||
-           (K == 128 && N == 256) || (K == 512 && N == 384);
+           (K == 128 && N == 256) || (K == 512 && N == 384) || (K == 96 && (N == 288 || N == 96 || N == 384)) || (K == 384 && N == 96) ||
+           (K == 288 && N == 96);
 }

@@ -176,6 +176,14 @@ def ws_supported(x, w, pool=False):
             and bool(lib.gm3d_gemm_ws_supported(w.shape[0], w.shape[1], int(pool))))
 
 
+WS_RAGGED = True         # ... and the ragged-K members (K = 96 / 288; N = 96 / 288 / 384): 25-28 us on the tiled kernels at 65,536 rows
+
+
+def ws_ragged_supported(x, w):
+    return (USE_WS and WS_RAGGED and ragged_supported(x, w) and x.shape[0] >= 32768
+            and (w.shape[0] % 128 != 0 or w.shape[1] % 64 != 0) and bool(lib.gm3d_gemm_ws_supported(w.shape[0], w.shape[1], 0)))
+
+
 def linear_tn_ws(x, w, bias=None, out=None):
     """linear_tn through the weight-stationary streaming kernel (csrc/gemm_ws.hip): bit-identical; for the tall mini-PointNet products."""
     M, K = x.shape
@@ -266,6 +274,8 @@ def mm(x, w, bias=None, out=None):
     """x (M,K) @ w (N,K)^T (+ bias) on the kernel `choose` names.  Operands that do not meet the hand-written kernels' layout
     rules (fp32 parity mode, odd widths) go to torch.mm: never on the bf16 step's path (tools/leftover_sites.py lists none)."""
     how = choose(x.shape[0], w.shape[0], w.shape[1]) if supported(x, w) else "lib"
+    if how == "lib" and ws_ragged_supported(x, w) and (out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0)):
+        return linear_tn_ws(x, w, bias, out)       # the 96-wide blocks over 65,536 token rows (Point-M2AE level 0): HBM streams
     if how == "lib" and ragged_supported(x, w) and (out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0)):
         # a ragged last column tile alone (K a multiple of the 64-column stage): the ring kernel; a ragged K as well: csrc/gemm.hip
         if w.shape[1] % 64 == 0:
