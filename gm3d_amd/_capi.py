@@ -103,6 +103,7 @@ SIGNATURES = {
                           ctypes.c_longlong, _vp],
     "gm3d_gemm_nt_splits": [_i, _i, _i, _i],
     "gm3d_radius_mask_bits": [_vp, _vp, _f, _i, _i, _vp, _vp],
+    "gm3d_attention_masked_set_wide": [_i],
     "gm3d_attention_masked_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_masked_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_mask_select": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _i, _vp],

@@ -88,9 +88,11 @@ __device__ __forceinline__ unsigned mask_word(const unsigned* mrow /* row i, or 
 }
 
 // ===================================================================== forward, bf16
-// grid (B*H, ceil(T/128)), 256 threads: wave w owns query tile 4*blockIdx.y + w.
-template <int HD>
-__global__ __launch_bounds__(256) void mattn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, const unsigned* __restrict__ mask,
+// grid (B*H, ceil(T / (32 NWV))), 64 NWV threads: wave w owns query tile NWV*blockIdx.y + w.  NWV = 8 where the images fit twice per
+// CU (HD <= 32): the K / V images of a head are staged once per 256 queries and a CU holds 16 waves -- a wave's key-tile loop is one
+// dependent chain (MFMA -> mask -> max -> exp -> sum -> MFMA), so what hides its latency is other waves (136 -> see profiles/ at T = 512).
+template <int HD, int NWV>
+__global__ __launch_bounds__(64 * NWV) void mattn_fwd_bf16_kernel(const bf16_t* __restrict__ qkv, const unsigned* __restrict__ mask,
                                                              bf16_t* __restrict__ out, float* __restrict__ lse, int T, int H, int W,
                                                              float scale) {
     extern __shared__ __attribute__((aligned(16))) unsigned char msm[];
@@ -106,10 +108,10 @@ __global__ __launch_bounds__(256) void mattn_fwd_bf16_kernel(const bf16_t* __res
     const int r = lane & 31, hh = lane >> 5;
     const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
     const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
-    const int q0 = 128 * blockIdx.y;
-    I::stage(Ki, Qg + os, rs, T, rowsK, tid, 256);
-    I::stage(Vi, Qg + 2 * os, rs, T, rowsK, tid, 256);
-    I::stage(Qi, Qg + (size_t)q0 * rs, rs, T - q0, 128, tid, 256);
+    const int q0 = 32 * NWV * blockIdx.y;
+    I::stage(Ki, Qg + os, rs, T, rowsK, tid, 64 * NWV);
+    I::stage(Vi, Qg + 2 * os, rs, T, rowsK, tid, 64 * NWV);
+    I::stage(Qi, Qg + (size_t)q0 * rs, rs, T - q0, 32 * NWV, tid, 64 * NWV);
     __syncthreads();
     const int q = q0 + 32 * w + r;                  // this lane's query
     if (q0 + 32 * w >= T) return;                   // whole tile past the end (wave-uniform)
@@ -181,9 +183,11 @@ __global__ __launch_bounds__(256) void mattn_fwd_bf16_kernel(const bf16_t* __res
 }
 
 // ===================================================================== backward, bf16
-// grid (B*H, ceil(T/128)), 512 threads: waves 0..3 own key tiles 4c + w (dK, dV), waves 4..7 own query tiles 4c + w - 4 (dQ).
-template <int HD>
-__global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const unsigned* __restrict__ mask,
+// grid (B*H, ceil(T / (32 NTP))), 128 NTP threads: waves 0..NTP-1 own key tiles NTP c + w (dK, dV), waves NTP..2 NTP-1 own query
+// tiles NTP c + w - NTP (dQ).  NTP = 8 (16 waves, one workgroup per CU) for HD <= 32: the four images of a head are staged half as
+// often and twice as many waves share a CU.
+template <int HD, int NTP>
+__global__ __launch_bounds__(128 * NTP) void mattn_bwd_bf16_kernel(const bf16_t* __restrict__ qkv, const unsigned* __restrict__ mask,
                                                              const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout,
                                                              const float* __restrict__ lse, bf16_t* __restrict__ dqkv, int T, int H,
                                                              int W, float scale) {
@@ -204,11 +208,12 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
     const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
     const bf16_t* Og = out + (size_t)b * T * os + (size_t)h * HD;
     const bf16_t* Dg = dout + (size_t)b * T * os + (size_t)h * HD;
-    I::stage(Qi, Qg, rs, T, rows, tid, 512);
-    I::stage(Ki, Qg + os, rs, T, rows, tid, 512);
-    I::stage(Vi, Qg + 2 * os, rs, T, rows, tid, 512);
-    I::stage(Di, Dg, os, T, rows, tid, 512);
-    for (int i = tid; i < rows; i += 512) {         // delta[q] = sum_d dO[q][d] * O[q][d]
+    constexpr int NTH = 128 * NTP;
+    I::stage(Qi, Qg, rs, T, rows, tid, NTH);
+    I::stage(Ki, Qg + os, rs, T, rows, tid, NTH);
+    I::stage(Vi, Qg + 2 * os, rs, T, rows, tid, NTH);
+    I::stage(Di, Dg, os, T, rows, tid, NTH);
+    for (int i = tid; i < rows; i += NTH) {         // delta[q] = sum_d dO[q][d] * O[q][d]
         float acc = 0.f;
         if (i < T) {
 #pragma unroll
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
     __syncthreads();
     bf16_t* dQg = dqkv + (size_t)b * T * rs + (size_t)h * HD;
     const int cb = 16 * ((lane >> 4) & 1);
-    const int tile = 4 * blockIdx.y + (w & 3);
+    const int tile = NTP * blockIdx.y + (w < NTP ? w : w - NTP);
     if (32 * tile >= T) return;                     // wave-uniform; no barrier follows
     const int row = 32 * tile + r;                  // this lane's key (waves 0..3) or query (waves 4..7)
     const bool row_ok = row < T;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
     mf32x16 x[DT], y[DT];
 #pragma unroll
     for (int d = 0; d < DT; ++d) { x[d] = mzero16(); y[d] = mzero16(); }
-    if (w < 4) {
+    if (w < NTP) {
         // phase A: X[q][key] tiles (rows = q in registers, cols = key on the lane); the mask is symmetric: row `key`, word qt
         mbf16x8 fk[KS], fv[KS];
 #pragma unroll
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
         }
     }
     if (row_ok) {
-        bf16_t* g0 = dQg + (size_t)row * rs + (w < 4 ? 2 * os : 0);       // dV (waves 0..3) / dQ (waves 4..7)
+        bf16_t* g0 = dQg + (size_t)row * rs + (w < NTP ? 2 * os : 0);     // dV (key waves) / dQ (query waves)
         bf16_t* g1 = dQg + (size_t)row * rs + os;                         // dK
 #pragma unroll
         for (int d = 0; d < DT; ++d)
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(512) void mattn_bwd_bf16_kernel(const bf16_t* __res
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { pk[e] = (bf16_t)x[d][4 * g4 + e]; pk2[e] = (bf16_t)y[d][4 * g4 + e]; }
                     *reinterpret_cast<mbf16x4*>(g0 + d0) = pk;
-                    if (w < 4) *reinterpret_cast<mbf16x4*>(g1 + d0) = pk2;
+                    if (w < NTP) *reinterpret_cast<mbf16x4*>(g1 + d0) = pk2;
                 }
             }
     }
@@ -436,26 +441,39 @@ __global__ __launch_bounds__(128) void mattn_bwd_f32_kernel(const float* __restr
 
 // mask bitset of one level straight from its centres: bit j of row i set iff token i or j is not visible, or their centres are
 // at squared distance >= radius^2 (same separately rounded fp32 expression as common.hpp::sqdist3 / the oracle).
-// One thread per (b, i, word).
+// grid (ceil(G W / 256), B): one thread per (i, word) of cloud blockIdx.y, the cloud's centres and visibility staged in LDS (the 32
+// partners of a word were 32 dependent global loads per thread: 110 us at B = 128, G = 512).
 __global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __restrict__ center, const unsigned char* __restrict__ vis,
                                                                float radius, int B, int G, int W, unsigned* __restrict__ bits) {
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= (long long)B * G * W) return;
-    const int wd = (int)(gid % W), i = (int)((gid / W) % G), b = (int)(gid / ((long long)W * G));
+    extern __shared__ float rsm[];               // x[G] | y[G] | z[G] | vis[G] (as float flags)
+    float* cx = rsm;
+    float* cy = cx + G;
+    float* cz = cy + G;
+    float* cv = cz + G;
+    const int b = blockIdx.y;
     const float* c = center + (size_t)b * G * 3;
+    for (int j = threadIdx.x; j < G; j += 256) {
+        cx[j] = c[3 * j]; cy[j] = c[3 * j + 1]; cz[j] = c[3 * j + 2];
+        cv[j] = (!vis || vis[(size_t)b * G + j]) ? 1.f : 0.f;
+    }
+    __syncthreads();
+    const int id = blockIdx.x * 256 + threadIdx.x;
+    if (id >= G * W) return;
+    const int wd = id % W, i = id / W;
     const float r2 = __fmul_rn(radius, radius);
-    const float ax = c[3 * i], ay = c[3 * i + 1], az = c[3 * i + 2];
-    const bool vi = !vis || vis[(size_t)b * G + i];
+    const float ax = cx[i], ay = cy[i], az = cz[i];
+    const bool vi = cv[i] != 0.f;
     unsigned w = 0;
     for (int t = 0; t < 32; ++t) {
         const int j = 32 * wd + t;
         bool blocked = true;
-        if (j < G && vi && (!vis || vis[(size_t)b * G + j]))
-            blocked = radius > 0.f && sqdist3(ax, ay, az, c[3 * j], c[3 * j + 1], c[3 * j + 2]) >= r2;
+        if (j < G && vi && cv[j] != 0.f) blocked = radius > 0.f && sqdist3(ax, ay, az, cx[j], cy[j], cz[j]) >= r2;
         w |= blocked ? (1u << t) : 0u;
     }
-    bits[gid] = w;
+    bits[(size_t)b * G * W + id] = w;
 }
+
+static int MATTN_WIDE = 1;      // 8 tiles per workgroup for HD <= 32, T > 128 (gm3d_attention_masked_set_wide: the A/B knob)
 
 static int mattn_check(const void* a, const void* b, int B, int T, int H, int HDv, int dtype) {
     if (!a || !b || B < 0 || T < 1 || H < 1) return GM3D_EINVAL;
@@ -476,15 +494,20 @@ static int mattn_attr(K kernel, size_t lds) {
 
 }  // namespace gm3d
 
+extern "C" int gm3d_attention_masked_set_wide(int on) {
+    gm3d::MATTN_WIDE = on ? 1 : 0;
+    return GM3D_OK;
+}
+
 extern "C" int gm3d_radius_mask_bits(const float* center, const unsigned char* vis, float radius, int B, int G, unsigned* bits,
                                      gm3d_stream_t stream) {
     using namespace gm3d;
     if (!center || !bits || B < 0 || G < 1) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;
     const int W = (G + 31) / 32;
-    const long long n = (long long)B * G * W;
-    hipLaunchKernelGGL(radius_mask_bits_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, center, vis, radius,
-                       B, G, W, bits);
+    if (G > 8192 || B > 65535) return GM3D_EUNSUPPORTED;
+    hipLaunchKernelGGL(radius_mask_bits_kernel, dim3((unsigned)((G * W + 255) / 256), (unsigned)B), dim3(256), (size_t)4 * G * sizeof(float),
+                       (hipStream_t)stream, center, vis, radius, B, G, W, bits);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
@@ -500,16 +523,19 @@ extern "C" int gm3d_attention_masked_fwd(const void* qkv, const unsigned* mask, 
     const int W = (T + 31) / 32;
     if (dtype == GM3D_BF16) {
         const int rowsK = 32 * W;
-        const size_t lds = (size_t)(2 * rowsK + 128) * (HD * 2 + 16);
-        const dim3 grid(B * H, (T + 127) / 128);
-#define GM3D_MF(HD_)                                                                                                   \
+        const int nwv = (HD <= 32 && T > 128 && MATTN_WIDE) ? 8 : 4;          // query tiles (= waves) per workgroup
+        const size_t lds = (size_t)(2 * rowsK + 32 * nwv) * (HD * 2 + 16);
+        const dim3 grid(B * H, (T + 32 * nwv - 1) / (32 * nwv));
+#define GM3D_MF(HD_, NWV_)                                                                                             \
     {                                                                                                                  \
-        rc = mattn_attr(mattn_fwd_bf16_kernel<HD_>, lds);                                                              \
+        rc = mattn_attr(mattn_fwd_bf16_kernel<HD_, NWV_>, lds);                                                        \
         if (rc != GM3D_OK) return rc;                                                                                  \
-        hipLaunchKernelGGL(mattn_fwd_bf16_kernel<HD_>, grid, dim3(256), lds, st, (const bf16_t*)qkv, mask, (bf16_t*)out, lse, T, H, W, \
-                           scale);                                                                                    \
+        hipLaunchKernelGGL((mattn_fwd_bf16_kernel<HD_, NWV_>), grid, dim3(64 * NWV_), lds, st, (const bf16_t*)qkv, mask, (bf16_t*)out, lse, \
+                           T, H, W, scale);                                                                           \
     }
-        if (HD == 16) GM3D_MF(16) else if (HD == 32) GM3D_MF(32) else GM3D_MF(64)
+        if (HD == 16) { if (nwv == 8) GM3D_MF(16, 8) else GM3D_MF(16, 4) }
+        else if (HD == 32) { if (nwv == 8) GM3D_MF(32, 8) else GM3D_MF(32, 4) }
+        else GM3D_MF(64, 4)
 #undef GM3D_MF
     } else {
         const long long n = (long long)B * H * T;
@@ -534,15 +560,18 @@ extern "C" int gm3d_attention_masked_bwd(const void* qkv, const unsigned* mask, 
     if (dtype == GM3D_BF16) {
         const int rows = 32 * W;
         const size_t lds = (size_t)4 * rows * (HD * 2 + 16) + (size_t)2 * rows * sizeof(float);
-        const dim3 grid(B * H, (T + 127) / 128);
-#define GM3D_MB(HD_)                                                                                                   \
+        const int ntp = (HD <= 32 && T > 128 && MATTN_WIDE) ? 8 : 4;          // key tiles (= query tiles) per workgroup
+        const dim3 grid(B * H, (T + 32 * ntp - 1) / (32 * ntp));
+#define GM3D_MB(HD_, NTP_)                                                                                             \
     {                                                                                                                  \
-        rc = mattn_attr(mattn_bwd_bf16_kernel<HD_>, lds);                                                              \
+        rc = mattn_attr(mattn_bwd_bf16_kernel<HD_, NTP_>, lds);                                                        \
         if (rc != GM3D_OK) return rc;                                                                                  \
-        hipLaunchKernelGGL(mattn_bwd_bf16_kernel<HD_>, grid, dim3(512), lds, st, (const bf16_t*)qkv, mask, (const bf16_t*)out,        \
+        hipLaunchKernelGGL((mattn_bwd_bf16_kernel<HD_, NTP_>), grid, dim3(128 * NTP_), lds, st, (const bf16_t*)qkv, mask, (const bf16_t*)out, \
                            (const bf16_t*)dout, lse, (bf16_t*)dqkv, T, H, W, scale);                                  \
     }
-        if (HD == 16) GM3D_MB(16) else if (HD == 32) GM3D_MB(32) else GM3D_MB(64)
+        if (HD == 16) { if (ntp == 8) GM3D_MB(16, 8) else GM3D_MB(16, 4) }
+        else if (HD == 32) { if (ntp == 8) GM3D_MB(32, 8) else GM3D_MB(32, 4) }
+        else GM3D_MB(64, 4)
 #undef GM3D_MB
     } else {
         const long long n = (long long)B * H * T;

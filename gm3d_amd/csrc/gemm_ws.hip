@@ -403,6 +403,9 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
     // rows): qkv / proj / fc1 / fc2 and their input gradients -- ragged K (96, 288) through the Kreal path
     if (K == 96 && N == 288) GM3D_WS_LAUNCH(2, 9, 1, 0, 1)           // qkv
     if (K == 96 && N == 96) GM3D_WS_LAUNCH(2, 3, 1, 0, 1)            // proj, and its input gradient
+    if (K == 96 && N == 512) GM3D_WS_LAUNCH(2, 8, 1, 0, 1)           // level-0 embed: second_conv.3's input gradient (1,048,576 rows)
+    if (K == 96 && N == 192) GM3D_WS_LAUNCH(2, 6, 1, 0, 1)           // level-1 token embed: second_conv.0 on the local half (262,144 rows)
+    if (K == 192 && N == 96) GM3D_WS_LAUNCH(3, 3, 1, 0, 1)           // ... and its input gradient
     if (K == 96 && N == 384) GM3D_WS_LAUNCH(2, 6, 1, 0, 1)           // fc1, fc2's input gradient (two column blocks of 192)
     if (K == 384 && N == 96) GM3D_WS_LAUNCH(6, 3, 1, 0, 1)           // fc2, fc1's input gradient
     if (K == 288 && N == 96) GM3D_WS_LAUNCH(5, 3, 1, 0, 1)           // qkv's input gradient
@@ -457,6 +460,6 @@ extern "C" int gm3d_gemm_ws_stats_rows(int M, int N, int K) {
 extern "C" int gm3d_gemm_ws_supported(int N, int K, int pool) {
     if (pool) return (K == 128 && N == 256) || (K == 512 && N == 384);
     return (K == 256 && N == 512) || (K == 512 && N == 256) || (K == 384 && N == 512) || (K == 256 && N == 128) ||
-           (K == 128 && N == 256) || (K == 512 && N == 384) || (K == 96 && (N == 288 || N == 96 || N == 384)) || (K == 384 && N == 96) ||
-           (K == 288 && N == 96);
+           (K == 128 && N == 256) || (K == 512 && N == 384) || (K == 96 && (N == 288 || N == 96 || N == 384 || N == 192 || N == 512)) || (K == 384 && N == 96) ||
+           (K == 288 && N == 96) || (K == 192 && N == 96);
 }

@@ -577,6 +577,8 @@ int gm3d_gather_rows_bwd_w(const void *dy, int ldy, int col0, int refs_per_row, 
  * elem_bytes 2 or 4.  Gather into / scatter out of the compact order above, forward and backward (indices without repeats). */
 int gm3d_select_rows(const void *a, const int *idx, const void *alt, void *out, int B, int Ta, int T, int C, int elem_bytes,
                      gm3d_stream_t stream);
+/* measurement knob: 1 (default) = eight 32-row tiles per workgroup for HD <= 32 and T > 128, 0 = four everywhere */
+int gm3d_attention_masked_set_wide(int on);
 int gm3d_attention_masked_fwd(const void *qkv, const unsigned *mask, void *out, float *lse, int B, int T, int H, int HD, float scale,
                               int dtype, gm3d_stream_t stream);
 int gm3d_attention_masked_bwd(const void *qkv, const unsigned *mask, const void *out, const void *dout, const float *lse, void *dqkv,

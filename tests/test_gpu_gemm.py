@@ -322,7 +322,7 @@ def test_gemm_ring96_equals_ring(M, K, N, bm):
                                    (102400, 512, 384), (33, 256, 512), (32 * 257 + 5, 512, 384),
                                    # ragged K (96, 288) and narrow N: the 96-wide blocks of the hierarchical encoder's level 0
                                    (65536, 96, 288), (65536, 96, 96), (65536, 96, 384), (65536, 384, 96), (65536, 288, 96),
-                                   (40001, 96, 288), (77, 288, 96), (32 * 300 + 9, 96, 384)])
+                                   (40001, 96, 288), (77, 288, 96), (32 * 300 + 9, 96, 384), (262144, 96, 192), (50000, 192, 96), (100000, 96, 512)])
 def test_gemm_weight_stationary_equals_tiled_kernels(M, K, N):
     """csrc/gemm_ws.hip (persistent workgroups, W fragments resident in registers, A streamed through an LDS ring by loader waves):
     the same accumulation order along K as the tiled kernels -> bit-identical products, with and without bias, ragged M, nothing

@@ -12,7 +12,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--narrow-attn", action="store_true", help="A/B: four tiles per workgroup in the masked attention kernels (the round-3 form)")
 a = ap.parse_args()
+if a.narrow_attn:
+    from gm3d_amd._capi import lib as _lib
+    _lib.gm3d_attention_masked_set_wide(0)
 E.enable_tuned_gemms()        # this model still hands its 96- / 288- / 576-wide products to the library (K % 64 != 0 or N % 128 != 0)
 torch.manual_seed(0)
 model = P.PointM2AE().cuda().train()
