@@ -21,20 +21,14 @@ class HierarchicalGroup(nn.Module):
         assert len(num_groups) == len(group_sizes)
         self.num_groups, self.group_sizes = tuple(num_groups), tuple(group_sizes)
 
-    def level(self, src, i):
-        """one level: src (B,S,3) -> (neighbourhood (B,G_i,k_i,3), centre (B,G_i,3), idx (B,G_i,k_i) int64 into src)"""
-        center = ops.fps(src, self.num_groups[i])[1]
-        nb, _, idx = ops.knn_group(src, center, self.group_sizes[i], return_idx=True)
-        return nb, center, idx
-
-    def forward(self, pts, first=0, last=None, src=None):
+    def forward(self, pts):
         """pts (B,N,3) f32 -> per level lists: neighbourhoods (B,G_l,k_l,3) centred on their centre, centres (B,G_l,3),
-        idx (B,G_l,k_l) int64 into the PREVIOUS level's points (level 0: the raw cloud; level l>0: level l-1's centres).
-        first / last / src: only the levels first .. last-1, starting from the previous level's centres `src`."""
+        idx (B,G_l,k_l) int64 into the PREVIOUS level's points (level 0: the raw cloud; level l>0: level l-1's centres)."""
         neighborhoods, centers, idxs = [], [], []
-        src = pts.contiguous() if src is None else src
-        for i in range(first, len(self.num_groups) if last is None else last):
-            nb, center, idx = self.level(src, i)
+        src = pts.contiguous()
+        for G, k in zip(self.num_groups, self.group_sizes):
+            center = ops.fps(src, G)[1]
+            nb, _, idx = ops.knn_group(src, center, k, return_idx=True)
             neighborhoods.append(nb)
             centers.append(center)
             idxs.append(idx)

@@ -48,8 +48,6 @@ FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming 
 FUSED_PROPAGATION = True  # token propagation: 3-NN interpolation + concatenation as one launch (heads.Interp3Fn), deterministic backward
 STACK_NODE = True         # a block stack as ONE autograd node (masked_stack.MaskedStackFn): the weight gradients of all its blocks in one
 #                           launch, one column-sum finish per kind, one transposing launch; FUSED_BLOCKS' per-op nodes are the cross-check
-OVERLAP_STUDENT = True    # pretrain_forward: levels 1-2 of the grouping and the student's level-0 token embed (neither depends on the
-#                           mask) on a side stream beside the teacher's pass, whose block stacks are chains of small launches
 VISIBLE_FIRST = True      # student pass: every level's stack runs on the visible tokens moved to the front of the cloud, cut to the
 #                           static bound the mask generator implies (12 of 64 -> 16, 96 of 256, all 512): the attention kernels skip the
 #                           filler tiles, levels 1-2 shrink to 3/8 and 1/4 of their rows.  Same results for visible tokens.
@@ -305,29 +303,6 @@ class TokenPropagation(nn.Module):
         return y.view(B, N, -1)
 
 
-_no_masks = {}
-
-
-def _no_mask(B, G, device):
-    """(B,G) all-False mask: a cached constant (read-only)"""
-    key = (B, G, str(device))
-    if key not in _no_masks:
-        if device.type == "cuda" and torch.cuda.is_current_stream_capturing():
-            return torch.zeros(B, G, dtype=torch.bool, device=device)      # (memory of a capture's pool must not outlive it)
-        _no_masks[key] = torch.zeros(B, G, dtype=torch.bool, device=device)
-    return _no_masks[key]
-
-
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
-
 def _pos_mlp(dim):
     return nn.Sequential(Linear(3, dim), nn.GELU(), Linear(dim, dim))
 
@@ -394,27 +369,13 @@ class PointM2AE(nn.Module):
         b0 = min(G[0], up(vis_count * k[2] * k[1], 32))
         return [b0, b1, b2]
 
-    def embed_level0(self, nb0):
-        """the level-0 token embed (B,G0,k0,3) -> (B,G0,C0): it depends on the grouping only, not on the mask"""
-        from . import heads
-        if nb0.is_cuda and FUSED_EMBED0 and heads._adt() == torch.bfloat16:
-            from . import embed
-            return embed.run_embed(self.token_embed[0], nb0)
-        return self.token_embed[0](nb0)
-
-    def encode(self, neighborhoods, centers, idxs, masks, vis_count=None, compact=False, tok0=None, before_level1=None):
+    def encode(self, neighborhoods, centers, idxs, masks, vis_count=None, compact=False):
         """-> per level: encoder outputs for every token position (only the visible ones are meaningful).
-        compact: run each level's stack in the visible-first order (masked_stack.partition_visible).
-        tok0: the level-0 token embed when the caller has computed it already (embed_level0); before_level1: called once before
-        the first use of the deeper levels' grouping (a caller that produced it on another stream waits for it there)."""
+        compact: run each level's stack in the visible-first order (masked_stack.partition_visible)."""
         outs, prev = [], None
         bounds = self._compact_bounds(vis_count) if compact else None
         for i in range(3):
-            if i == 1 and before_level1 is not None:
-                before_level1()
-            if i == 0 and tok0 is not None:
-                tok = tok0
-            elif i == 0:
+            if i == 0:
                 from . import heads
                 if neighborhoods[0].is_cuda and FUSED_EMBED0 and heads._adt() == torch.bfloat16:
                     # the level-0 embed has Point-MAE's layer structure (xyz in, 16-point groups): the north-star model's fused
@@ -452,7 +413,7 @@ class PointM2AE(nn.Module):
             prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
         return outs
 
-    def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None, tok0=None, before_level1=None):
+    def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None):
         """pts (B,N,3) f32; mask (B,64) bool over the COARSEST tokens (True = masked; None: nothing masked).
         vis_count: the number of visible coarsest tokens of EVERY cloud when the caller knows it (generate_mask_ids keeps exactly
         len_keep): a static bound for the visible-first order; a wrong bound sets masked_stack.overflow_flag.
@@ -460,16 +421,10 @@ class PointM2AE(nn.Module):
         neighborhoods, centers, idxs = group if group is not None else self.group_divider(pts)
         B = centers[0].shape[0]
         compact = VISIBLE_FIRST and STACK_NODE and FUSED_BLOCKS and mask is not None and centers[0].is_cuda
-        if mask is None:      # nothing masked at any level: no back-projection (and no early read of the deeper levels' member lists)
-            masks = [_no_mask(B, c.shape[1], c.device) for c in centers]
-            mask = masks[-1]
-        else:
-            if before_level1 is not None:
-                before_level1()
-                before_level1 = None
-            masks = back_project(mask, idxs)
-        enc = self.encode(neighborhoods, centers, idxs, masks, vis_count=vis_count, compact=compact, tok0=tok0,
-                          before_level1=before_level1)
+        if mask is None:
+            mask = torch.zeros(B, self.num_group, dtype=torch.bool, device=centers[0].device)
+        masks = back_project(mask, idxs)
+        enc = self.encode(neighborhoods, centers, idxs, masks, vis_count=vis_count, compact=compact)
         vis2, vis1 = ~masks[2], ~masks[1]
         x2 = self.encoder_norms[2](enc[2])
         if noaug:
@@ -525,41 +480,13 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
     masked, the guided mask (P/models_mae_learn_loss.py:744-784 with this model's mask ratio) hides the hardest ones, the student
     reconstructs and predicts its own per-token loss.  -> dict with `loss`, `loss_chfr`, `loss_learn`, `mask`."""
     raw = model.module if hasattr(model, "module") else model
-    tok0, side = None, None
-    if OVERLAP_STUDENT and group is None and pts.is_cuda:
-        # Level 0 of the grouping here; levels 1-2 and the student's level-0 embed on a side stream while the teacher runs (its
-        # level-0 embed needs level 0 only).  The teacher waits for the deeper levels where it first reads them.
-        from . import streams
-        gd = teacher.group_divider
-        main = torch.cuda.current_stream()
-        with torch.no_grad():
-            nb0, c0, i0 = gd.level(pts.contiguous(), 0)
-        side = _side_stream(pts.device)
-        streams.fork(side, main, who="point_m2ae.pretrain_forward: deeper grouping + student level-0 embed beside the teacher")
-        with torch.cuda.stream(side):
-            with torch.no_grad():
-                nbs, cs, ids = gd(None, first=1, src=c0)
-            ready = torch.cuda.Event()
-            ready.record(side)
-            tok0 = raw.embed_level0(nb0)                    # grad mode as the caller set it: the student's own embed
-        for t_ in (nb0, c0):
-            t_.record_stream(side)
-        for t_ in list(nbs) + list(cs) + list(ids) + [tok0]:
-            t_.record_stream(main)
-        group = ([nb0] + nbs, [c0] + cs, [i0] + ids)
-        gate = lambda: main.wait_event(ready)
-    else:
-        gate = None
     with torch.no_grad():
         group = group if group is not None else teacher.group_divider(pts)
-        t = teacher(pts, mask=None, group=group, before_level1=gate)
+        t = teacher(pts, mask=None, group=group)
         mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
                                                       total_epoch=total_epoch, noise=mask_noise)
         masked = mask.to(torch.bool)
-    if side is not None:
-        from . import streams
-        streams.join(side)
-    out = model(pts, mask=masked, group=group, vis_count=vis_ids.shape[1], tok0=tok0)
+    out = model(pts, mask=masked, group=group, vis_count=vis_ids.shape[1])
     lo = raw.forward_loss(out["rec"], group[0], group[2], out["masks"])
     pred = M.take(out["loss_pred"].float(), mask_ids)
     target = M.take(lo["matrix"].detach().float(), mask_ids)

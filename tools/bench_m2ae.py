@@ -12,11 +12,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
-ap.add_argument("--no-overlap", action="store_true", help="A/B: no side stream beside the teacher's pass")
 ap.add_argument("--narrow-attn", action="store_true", help="A/B: four tiles per workgroup in the masked attention kernels (the round-3 form)")
 a = ap.parse_args()
-if a.no_overlap:
-    P.OVERLAP_STUDENT = False
 if a.narrow_attn:
     from gm3d_amd._capi import lib as _lib
     _lib.gm3d_attention_masked_set_wide(0)
