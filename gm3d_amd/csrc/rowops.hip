@@ -338,176 +338,6 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
     }
 }
 
-// ------------------------------------------------------------------ the same two kernels for widths C <= 128 (one quad per lane)
-// Level 0 of the hierarchical encoder runs 96-wide rows, 65,536 of them: with one row per half-wave and iteration a wave has 400 bytes
-// per tensor in flight and the passes are latency-bound (19 us forward, 45 us backward for 63 / 88 MB).  Here a half-wave works on RU = 4
-// rows per iteration -- every load of the four rows is issued before the first reduction -- with the arithmetic per row unchanged.
-constexpr int LN_RU = 4;
-
-template <class T>
-__global__ __launch_bounds__(256) void ln_narrow_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, float eps, T* __restrict__ h,
-                                                            float* __restrict__ mean, float* __restrict__ rstd, int R, int C,
-                                                            const T* __restrict__ y, const float* __restrict__ ybias,
-                                                            const float* __restrict__ rowscale, int rows_per_sample,
-                                                            const T* __restrict__ z, T* __restrict__ s_out) {
-    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5;
-    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * LN_RU;
-    const int stride = gridDim.x * 8 * LN_RU;
-    const float invc = 1.0f / (float)C;
-    const int c = 4 * hl;
-    const bool on = c < C;
-    float g[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f}, yb[4] = {0.f, 0.f, 0.f, 0.f};
-    if (on && gamma) { Quad<float>::load(gamma + c, g); Quad<float>::load(beta + c, b); }
-    if (on && ybias) Quad<float>::load(ybias + c, yb);
-    for (int rb = wbase; rb < R; rb += stride) {
-        float v[LN_RU][4], ty[LN_RU][4], tz[LN_RU][4], rsc[LN_RU];
-        bool valid[LN_RU];
-        size_t base[LN_RU];
-#pragma unroll
-        for (int u = 0; u < LN_RU; ++u) {
-            const int rr = rb + 2 * u + half;
-            valid[u] = rr < R;
-            const int r = valid[u] ? rr : R - 1;
-            base[u] = (size_t)r * C;
-            rsc[u] = (y && rowscale) ? rowscale[r / rows_per_sample] : 1.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[u][j] = ty[u][j] = tz[u][j] = 0.f;
-            if (on) {
-                Quad<T>::load(x + base[u] + c, v[u]);
-                if (y) Quad<T>::load(y + base[u] + c, ty[u]);
-                if (z) Quad<T>::load(z + base[u] + c, tz[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LN_RU; ++u) {
-            if (on) {
-                if (y) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][j] += rsc[u] * (ty[u][j] + yb[j]);
-                }
-                if (z) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][j] += tz[u][j];
-                }
-                if (s_out) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[u][j] = (float)(T)v[u][j];
-                    if (valid[u]) Quad<T>::store(s_out + base[u] + c, v[u]);
-                }
-            }
-            if (!gamma) continue;
-            const float s = (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
-            const float mu = half_sum(s, lane) * invc;
-            float q = 0.f;
-            if (on) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = v[u][j] - mu; q += d * d; }
-            }
-            const float rsd = rsqrtf(half_sum(q, lane) * invc + eps);
-            if (on) {
-                float o[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (v[u][j] - mu) * rsd * g[j] + b[j];
-                if (valid[u]) Quad<T>::store(h + base[u] + c, o);
-            }
-            if (hl == 0 && valid[u]) { mean[base[u] / C] = mu; rstd[base[u] / C] = rsd; }
-        }
-    }
-}
-
-template <class T>
-__global__ __launch_bounds__(256) void ln_narrow_bwd_kernel(const T* __restrict__ dh, const T* __restrict__ x,
-                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                            const float* __restrict__ gamma, T* __restrict__ dx,
-                                                            float* __restrict__ partial, int R, int C,
-                                                            const T* __restrict__ gin, const float* __restrict__ rowscale,
-                                                            int rows_per_sample, T* __restrict__ dy, int nsum,
-                                                            T* __restrict__ acc, int acc_mode) {
-    __shared__ float red[8][3 * 128];
-    const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, slot = (threadIdx.x >> 6) * 2 + half;
-    const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 * LN_RU;
-    const int stride = gridDim.x * 8 * LN_RU;
-    const float invc = 1.0f / (float)C;
-    const int c = 4 * hl;
-    const bool on = c < C;
-    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f}, sy[4] = {0.f, 0.f, 0.f, 0.f}, gm[4] = {0.f, 0.f, 0.f, 0.f};
-    if (on && dh) Quad<float>::load(gamma + c, gm);
-    for (int rb = wbase; rb < R; rb += stride) {
-        float d[LN_RU][4], xh[LN_RU][4], gq[LN_RU][4], aq[LN_RU][4], mu[LN_RU], rs[LN_RU], rsc[LN_RU];
-        bool valid[LN_RU];
-        size_t base[LN_RU];
-#pragma unroll
-        for (int u = 0; u < LN_RU; ++u) {
-            const int rr = rb + 2 * u + half;
-            valid[u] = rr < R;
-            const int r = valid[u] ? rr : R - 1;
-            base[u] = (size_t)r * C;
-            mu[u] = dh ? mean[r] : 0.f;
-            rs[u] = dh ? rstd[r] : 0.f;
-            rsc[u] = rowscale ? rowscale[r / rows_per_sample] : 1.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { d[u][j] = 0.f; xh[u][j] = mu[u]; gq[u][j] = 0.f; aq[u][j] = 0.f; }
-            if (on) {
-                if (dh) { Quad<T>::load(dh + base[u] + c, d[u]); Quad<T>::load(x + base[u] + c, xh[u]); }
-                if (gin) Quad<T>::load(gin + base[u] + c, gq[u]);
-                if (acc_mode == 2) Quad<T>::load(acc + base[u] + c, aq[u]);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < LN_RU; ++u) {
-            float a = 0.f, b = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                xh[u][j] = (xh[u][j] - mu[u]) * rs[u];
-                const float g = d[u][j] * gm[j];
-                a += g;
-                b += g * xh[u][j];
-            }
-            const float m1 = half_sum(a, lane) * invc, m2 = half_sum(b, lane) * invc;
-            if (!on) continue;
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                o[j] = dh ? gq[u][j] + rs[u] * (d[u][j] * gm[j] - m1 - xh[u][j] * m2) : gq[u][j];
-                if (valid[u]) { sg[j] += d[u][j] * xh[u][j]; sb[j] += d[u][j]; }
-            }
-            if (valid[u]) Quad<T>::store(dx + base[u] + c, o);
-            if (acc_mode && valid[u]) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) aq[u][j] += (float)(T)o[j];
-                Quad<T>::store(acc + base[u] + c, aq[u]);
-            }
-            if (nsum == 3) {
-                float oy[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    oy[j] = (float)(T)(rsc[u] * (float)(T)o[j]);
-                    if (valid[u]) sy[j] += oy[j];
-                }
-                if (valid[u] && dy) Quad<T>::store(dy + base[u] + c, oy);
-            } else if (dy && valid[u]) {
-                float oy[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) oy[j] = rsc[u] * (float)(T)o[j];
-                Quad<T>::store(dy + base[u] + c, oy);
-            }
-        }
-    }
-    if (on) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[j]; red[slot][128 + c + j] = sb[j]; red[slot][256 + c + j] = sy[j]; }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < nsum * C; t += 256) {
-        const int which = t / C, cc = t - which * C;
-        float a = 0.f;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) a += red[k][which * 128 + cc];
-        partial[((size_t)blockIdx.x * nsum + which) * C + cc] = a;
-    }
-}
-
 // Backward of residual_ln_fwd_kernel for one LayerNorm site.
 //   xhat = (x - mean) * rstd,  g = dh * gamma
 //   dx   = gin + rstd * (g - mean_c(g) - xhat * mean_c(g * xhat))          (grad wrt out_res)
@@ -770,7 +600,6 @@ __global__ __launch_bounds__(256) void sum_few_rows_kernel(const float* __restri
 static inline int ln_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 512 ? 512 : g); }
 static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
 static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
-static int LN_NARROW = 1;      // widths <= 128 on the four-rows-per-half-wave kernels (gm3d_ln_set_narrow: the A/B knob)
 
 }  // namespace gm3d
 
@@ -820,11 +649,6 @@ extern "C" int gm3d_residual_ln_bwd(const void* dh, const float* gin, const floa
     return GM3D_OK;
 }
 
-extern "C" int gm3d_ln_set_narrow(int on) {
-    gm3d::LN_NARROW = on ? 1 : 0;
-    return GM3D_OK;
-}
-
 extern "C" int gm3d_ln_plain_partial_rows(int R) { return R < 1 ? 0 : gm3d::ln_grid(R); }
 
 extern "C" int gm3d_add_ln_fwd(const void* x, const void* y, const float* ybias, const float* rowscale, int rows_per_sample, const void* z,
@@ -853,16 +677,6 @@ extern "C" int gm3d_add_ln_fwd(const void* x, const void* y, const float* ybias,
 #define GM3D_LNP_F(T_, NQ_) hipLaunchKernelGGL((ln_plain_fwd_kernel<T_, NQ_>), dim3(ln_fwd_grid(R)), dim3(256), 0, st, (const T_*)x, gamma, \
                                                beta, eps, (T_*)h, mean, rstd, R, C, (const T_*)y, ybias, rowscale, rows_per_sample,      \
                                                (const T_*)z, (T_*)s_out)
-    if (nq == 1 && LN_NARROW) {
-        if (dtype == GM3D_BF16)
-            hipLaunchKernelGGL(ln_narrow_fwd_kernel<bf16_t>, dim3(ln_fwd_grid((R + LN_RU - 1) / LN_RU)), dim3(256), 0, st, (const bf16_t*)x, gamma, beta,
-                               eps, (bf16_t*)h, mean, rstd, R, C, (const bf16_t*)y, ybias, rowscale, rows_per_sample, (const bf16_t*)z, (bf16_t*)s_out);
-        else
-            hipLaunchKernelGGL(ln_narrow_fwd_kernel<float>, dim3(ln_fwd_grid((R + LN_RU - 1) / LN_RU)), dim3(256), 0, st, (const float*)x, gamma, beta,
-                               eps, (float*)h, mean, rstd, R, C, (const float*)y, ybias, rowscale, rows_per_sample, (const float*)z, (float*)s_out);
-        GM3D_CHECK_LAUNCH();
-        return GM3D_OK;
-    }
     if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_F(bf16_t, 1); else if (nq == 2) GM3D_LNP_F(bf16_t, 2); else if (nq == 3) GM3D_LNP_F(bf16_t, 3); else GM3D_LNP_F(bf16_t, 4); }
     else { if (nq == 1) GM3D_LNP_F(float, 1); else if (nq == 2) GM3D_LNP_F(float, 2); else if (nq == 3) GM3D_LNP_F(float, 3); else GM3D_LNP_F(float, 4); }
 #undef GM3D_LNP_F
@@ -904,16 +718,6 @@ extern "C" int gm3d_add_ln_bwd_acc(const void* dh, const void* gin, const void* 
 #define GM3D_LNP_B(T_, NQ_) hipLaunchKernelGGL((ln_plain_bwd_kernel<T_, NQ_>), dim3(ln_grid(R)), dim3(256), 0, st, (const T_*)dh, (const T_*)x, \
                                                mean, rstd, gamma, (T_*)dx, partial, R, C, (const T_*)gin, rowscale, rows_per_sample,     \
                                                (T_*)dy, nsum, (T_*)acc, acc_mode)
-    if (nq == 1 && LN_NARROW) {      // the grid stays ln_grid(R): every block writes its row of the partial sums
-        if (dtype == GM3D_BF16)
-            hipLaunchKernelGGL(ln_narrow_bwd_kernel<bf16_t>, dim3(ln_grid(R)), dim3(256), 0, st, (const bf16_t*)dh, (const bf16_t*)x, mean, rstd, gamma,
-                               (bf16_t*)dx, partial, R, C, (const bf16_t*)gin, rowscale, rows_per_sample, (bf16_t*)dy, nsum, (bf16_t*)acc, acc_mode);
-        else
-            hipLaunchKernelGGL(ln_narrow_bwd_kernel<float>, dim3(ln_grid(R)), dim3(256), 0, st, (const float*)dh, (const float*)x, mean, rstd, gamma,
-                               (float*)dx, partial, R, C, (const float*)gin, rowscale, rows_per_sample, (float*)dy, nsum, (float*)acc, acc_mode);
-        GM3D_CHECK_LAUNCH();
-        return GM3D_OK;
-    }
     if (dtype == GM3D_BF16) { if (nq == 1) GM3D_LNP_B(bf16_t, 1); else if (nq == 2) GM3D_LNP_B(bf16_t, 2); else if (nq == 3) GM3D_LNP_B(bf16_t, 3); else GM3D_LNP_B(bf16_t, 4); }
     else { if (nq == 1) GM3D_LNP_B(float, 1); else if (nq == 2) GM3D_LNP_B(float, 2); else if (nq == 3) GM3D_LNP_B(float, 3); else GM3D_LNP_B(float, 4); }
 #undef GM3D_LNP_B

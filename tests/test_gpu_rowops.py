@@ -205,35 +205,3 @@ def test_bias_gelu_fn(adt, tol):
     ref.backward(go.double())
     rel = lambda a, r: float((a.double() - r).abs().max()) / float(r.abs().max())
     assert rel(out, ref) <= tol and rel(f.grad, f6.grad) <= tol and rel(bias.grad, b6.grad) <= tol
-
-
-@pytest.mark.parametrize("adt", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C,R", [(96, 65536 + 13), (100, 77), (128, 4100), (4, 9)])
-def test_narrow_layer_norm_kernels_equal_the_general_ones(adt, C, R):
-    """Widths <= 128 run on the four-rows-per-half-wave kernels (csrc/rowops.hip ln_narrow_*): per row the arithmetic of the general
-    kernels -> s, h, dx, dy bit-identical; the column sums meet in another order (1e-6 / bf16 steps)."""
-    from gm3d_amd import heads
-    from gm3d_amd._capi import lib
-    B = 1
-    g = torch.Generator(device="cuda").manual_seed(C + R)
-    rnd = lambda *sh: torch.randn(*sh, device="cuda", generator=g)
-    x0, y0, z0 = rnd(B, R, C).to(adt), rnd(B, R, C).to(adt), rnd(B, R, C).to(adt)
-    yb0, w0, b0 = rnd(C) * 0.5, 1 + 0.2 * rnd(C), 0.2 * rnd(C)
-    rs = torch.full((B,), 1.25, device="cuda")
-    gs, gh = rnd(B, R, C).to(adt), rnd(B, R, C).to(adt)
-    res = {}
-    try:
-        for narrow in (1, 0):
-            lib.gm3d_ln_set_narrow(narrow)
-            x, y, z = (t.clone().requires_grad_(True) for t in (x0, y0, z0))
-            yb, w, b = (t.clone().requires_grad_(True) for t in (yb0, w0, b0))
-            s, h = heads.AddLayerNormFn.apply(x, y, yb, rs, z, w, b, 1e-5, adt)
-            (s.float() * gs.float()).sum().add((h.float() * gh.float()).sum()).backward()
-            res[narrow] = (s.detach(), h.detach(), x.grad, y.grad, z.grad, yb.grad, w.grad, b.grad)
-    finally:
-        lib.gm3d_ln_set_narrow(1)
-    for i in range(5):
-        assert torch.equal(res[1][i], res[0][i]), i
-    for i in range(5, 8):
-        a, r = res[1][i].double(), res[0][i].double()
-        assert float((a - r).abs().max()) <= 2e-5 * float(r.abs().max()) + 1e-6, i
