@@ -459,7 +459,8 @@ __global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __re
     __syncthreads();
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id >= G * W) return;
-    const int wd = id % W, i = id / W;
+    const int wd = id / G, i = id - wd * G;         // lanes = consecutive rows i of ONE word: the partner j is the same for the whole wave (LDS
+    //                                                  broadcast); with lanes = consecutive words the 16 partners 32 floats apart share a bank
     const float r2 = __fmul_rn(radius, radius);
     const float ax = cx[i], ay = cy[i], az = cz[i];
     const bool vi = cv[i] != 0.f;
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __re
         if (j < G && vi && cv[j] != 0.f) blocked = radius > 0.f && sqdist3(ax, ay, az, cx[j], cy[j], cz[j]) >= r2;
         w |= blocked ? (1u << t) : 0u;
     }
-    bits[(size_t)b * G * W + id] = w;
+    bits[((size_t)b * G + i) * W + wd] = w;
 }
 
 static int MATTN_WIDE = 1;      // 8 tiles per workgroup for HD <= 32, T > 128 (gm3d_attention_masked_set_wide: the A/B knob)

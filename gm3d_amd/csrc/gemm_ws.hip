@@ -75,7 +75,9 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                                                                      const float* __restrict__ bias, bf16_t* __restrict__ C, int M, int N,
                                                                      int lda, int ldw, int ldc, int tiles_n, bf16_t* __restrict__ P,
                                                                      uint8_t* __restrict__ ARG, int ldp, int bias_after_pool, WsBn bn,
-                                                                     int Kreal) {
+                                                                     int Kreal, int pool16) {
+    // pool16 (EPI 3): groups of 16 rows -- a 32-row tile holds two groups, rows 0..15 and 16..31 (the hierarchical model's level-0
+    // groups of 16 points); P / ARG then have M / 16 rows and ARG counts within its group.
     // Kreal <= 64 KT: the true K (a multiple of 8) when it is not a multiple of the 64-column images (the hierarchical model's 96- and
     // 288-wide products).  Columns past it are never read: the loader's pieces there re-read column 0 of the same row (finite wherever
     // the row is), and the resident W fragments are zero from Kreal on, so those k contribute exactly 0.
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             unsigned short rowbits[TM][16];
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                unsigned best = 0;
+                unsigned best = 0, best2 = 0;           // best2: rows 16..31 when the tile holds two 16-row groups (g >= 8 <=> row >= 16)
 #pragma unroll
                 for (int g = 0; g < 16; ++g) {
                     const bf16_t o = (bf16_t)(acc[t][g] + (bias_in_tile ? bcol : 0.f));
@@ -238,20 +240,37 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                     u = u == 0x80000000u ? 0u : u;
                     const unsigned k = (u ^ (unsigned)(((int)u >> 31) | (int)0x80000000)) & 0xffff0000u;
                     const unsigned key = k | (unsigned)(31 - (8 * (g >> 2) + 4 * hh + (g & 3)));
-                    best = key > best ? key : best;
+                    if (pool16 && g >= 8) best2 = key > best2 ? key : best2;
+                    else best = key > best ? key : best;
                 }
-                {   // the other 16 rows of this column sit in lane ^ 32
+                {   // the other rows of this column sit in lane ^ 32
                     const unsigned other = (unsigned)__shfl_xor((int)best, 32);
                     best = other > best ? other : best;
+                    const unsigned other2 = (unsigned)__shfl_xor((int)best2, 32);
+                    best2 = other2 > best2 ? other2 : best2;
                 }
                 if (hh == 0 && m0 + 32 * t < M) {
                     const unsigned k = best & 0xffff0000u;
                     const unsigned u = (k & 0x80000000u) ? (k & 0x7fff0000u) : (~k & 0xffff0000u);
                     float v = __builtin_bit_cast(float, u);
                     if (bias_after_pool) v += bcol;
-                    const size_t o = (size_t)((m0 >> 5) + t) * ldp + n0 + 32 * w + r;
-                    P[o] = (bf16_t)v;
-                    ARG[o] = (uint8_t)(31u - (best & 0xffu));
+                    if (!pool16) {
+                        const size_t o = (size_t)((m0 >> 5) + t) * ldp + n0 + 32 * w + r;
+                        P[o] = (bf16_t)v;
+                        ARG[o] = (uint8_t)(31u - (best & 0xffu));
+                    } else {
+                        const size_t o = (size_t)((m0 >> 4) + 2 * t) * ldp + n0 + 32 * w + r;
+                        P[o] = (bf16_t)v;
+                        ARG[o] = (uint8_t)(31u - (best & 0xffu));                 // rows 0..15
+                        if (m0 + 32 * t + 16 < M) {
+                            const unsigned k2 = best2 & 0xffff0000u;
+                            const unsigned u2 = (k2 & 0x80000000u) ? (k2 & 0x7fff0000u) : (~k2 & 0xffff0000u);
+                            float v2 = __builtin_bit_cast(float, u2);
+                            if (bias_after_pool) v2 += bcol;
+                            P[o + ldp] = (bf16_t)v2;
+                            ARG[o + ldp] = (uint8_t)(15u - (best2 & 0xffu));      // 31 - (best2 & 0xff) = row in 16..31 -> minus 16
+                        }
+                    }
                 }
             }
             if (!C) continue;                        // no rows wanted (second_conv.3): nothing is staged
@@ -357,10 +376,11 @@ static int ws_grid(int tiles_m, int tiles_n, size_t lds) {
 }
 
 static int ws_launch(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* ARG, int M, int N, int K, int lda,
-                     int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream, int bn_mode = 0, gm3d::WsBn bn = gm3d::WsBn()) {
+                     int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream, int bn_mode = 0, gm3d::WsBn bn = gm3d::WsBn(),
+                     int pool16 = 0) {
     using namespace gm3d;
     if (!A || !W || (!C && !P) || M < 0 || N < 1 || K < 1) return GM3D_EINVAL;
-    if (P && (!ARG || M % 32 || ldp % 8 || ldp < N || ((size_t)ARG & 7) || ((size_t)P & 15))) return GM3D_EINVAL;
+    if (P && (!ARG || M % (pool16 ? 16 : 32) || ldp % 8 || ldp < N || ((size_t)ARG & 7) || ((size_t)P & 15))) return GM3D_EINVAL;
     if (K % 8 || K > 512 || lda % 8 || ldw % 8 || lda < K || ldw < K || (C && (ldc % 8 || ldc < N))) return GM3D_EUNSUPPORTED;
     if (((size_t)A | (size_t)W | (size_t)C) & 15) return GM3D_EUNSUPPORTED;
     if (M == 0) return GM3D_OK;
@@ -376,7 +396,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         if (!attr.ensure((const void*)gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>, lds)) return GM3D_ELAUNCH;                 \
         hipLaunchKernelGGL((gemm_tn_ws_kernel<KT, NW, NL, EPI, TM>), dim3(grid), dim3(64 * (NW + NL)), lds, st,          \
                            (const bf16_t*)A, (const bf16_t*)W, bias, (bf16_t*)C, M, N, lda, ldw, ldc, tiles_n, (bf16_t*)P, ARG, ldp, \
-                           bias_after_pool, bn, K);                                                                      \
+                           bias_after_pool, bn, K, pool16);                                                              \
         GM3D_CHECK_LAUNCH();                                                                                             \
         return GM3D_OK;                                                                                                  \
     }
@@ -385,6 +405,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         // (TM = 2 -- two sub-tiles per slot, two accumulator chains per wave -- measured no faster on any shape: TM = 1 everywhere)
         if (K == 128 && N == 256) GM3D_WS_LAUNCH(2, 8, 1, 3, 1)       // first_conv.3 + max-pool
         if (K == 512 && N == 384) GM3D_WS_LAUNCH(8, 6, 2, 3, 1)       // second_conv.3 + max-pool (two column blocks of 192)
+        if (K == 512 && N == 96) GM3D_WS_LAUNCH(8, 3, 2, 3, 1)        // ... of the hierarchical model's level 0 (96-wide tokens)
         return GM3D_EUNSUPPORTED;
     }
     if (bn_mode) {                                                    // second_conv.0 with the BatchNorm that follows it (EPI 4 / 5)
@@ -425,6 +446,14 @@ extern "C" int gm3d_gemm_tn_bf16_ws_pool(const void* A, const void* W, const flo
     return ws_launch(A, W, bias, C, P, arg, M, N, K, lda, ldw, ldc, ldp, bias_after_pool, stream);
 }
 
+// the same with groups of `group_rows` = 16 or 32 rows: P / arg (M / group_rows, N)
+extern "C" int gm3d_gemm_tn_bf16_ws_poolg(const void* A, const void* W, const float* bias, void* C, void* P, uint8_t* arg, int M, int N,
+                                          int K, int lda, int ldw, int ldc, int ldp, int bias_after_pool, int group_rows,
+                                          gm3d_stream_t stream) {
+    if (!P || !arg || (group_rows != 16 && group_rows != 32)) return GM3D_EINVAL;
+    return ws_launch(A, W, bias, C, P, arg, M, N, K, lda, ldw, ldc, ldp, bias_after_pool, stream, 0, gm3d::WsBn(), group_rows == 16);
+}
+
 // C = act((bf16(A.W^T) + T[row / 32]) * scale + shift), act(h) = h > 0 ? h : slope h: the product, the per-group term of the split
 // concat and an eval-mode BatchNorm + ReLU in one launch (T (M / 32, N) bf16, scale / shift (N) f32).  M % 32 == 0.
 extern "C" int gm3d_gemm_tn_bf16_ws_bn_apply(const void* A, const void* W, const void* T, const float* scale, const float* shift, float slope,
@@ -458,7 +487,7 @@ extern "C" int gm3d_gemm_ws_stats_rows(int M, int N, int K) {
 
 // 1 when gm3d_gemm_tn_bf16_ws[_pool] has an instantiation for (N, K)
 extern "C" int gm3d_gemm_ws_supported(int N, int K, int pool) {
-    if (pool) return (K == 128 && N == 256) || (K == 512 && N == 384);
+    if (pool) return (K == 128 && N == 256) || (K == 512 && N == 384) || (K == 512 && N == 96);
     return (K == 256 && N == 512) || (K == 512 && N == 256) || (K == 384 && N == 512) || (K == 256 && N == 128) ||
            (K == 128 && N == 256) || (K == 512 && N == 384) || (K == 96 && (N == 288 || N == 96 || N == 384 || N == 192 || N == 512)) || (K == 384 && N == 96) ||
            (K == 288 && N == 96) || (K == 192 && N == 96);

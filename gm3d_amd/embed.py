@@ -128,9 +128,9 @@ class EmbedFn(torch.autograd.Function):
                 _ptr(bf), _ptr(a1), R, C1, dt_id, _stream())
         # ---- conv2 + max-pool ----
         W2 = weight_cache.get(w2, adt).reshape(C2, C1)
-        pool_fused = gemm.FUSE_POOL and K == 32 and gemm.supported(a1, W2)
+        pool_fused = gemm.FUSE_POOL and ((K == 32 and gemm.supported(a1, W2)) or (K == 16 and gemm.pool16_supported(a1, W2)))
         if pool_fused:      # conv2 + bias + max-pool in one launch: f is written for conv3, (fg, arg1) come from the same tile
-            f, fg, arg1 = gemm.linear_pool(a1, W2, _c32(b2), bias_after_pool=False, want_rows=True)
+            f, fg, arg1 = gemm.linear_pool(a1, W2, _c32(b2), bias_after_pool=False, want_rows=True, group_rows=K)
         else:
             f = gemm.mm(a1, W2, _c32(b2)) if adt == torch.bfloat16 else torch.addmm(weight_cache.get(b2, adt), a1, W2.t())
             fg = torch.empty(BG, C2, dtype=adt, device=dev)
@@ -186,9 +186,9 @@ class EmbedFn(torch.autograd.Function):
         # ---- conv4 + max-pool ----
         W4 = weight_cache.get(w4, adt).reshape(C4, C3)
         b4f = _c32(b4)
-        if gemm.FUSE_POOL and K == 32 and gemm.supported(a2, W4):
+        if gemm.FUSE_POOL and ((K == 32 and gemm.supported(a2, W4)) or (K == 16 and gemm.pool16_supported(a2, W4))):
             # conv4 + max-pool + bias: the (rows, 384) product never reaches HBM (the backward needs only arg2)
-            _, tok, arg2 = gemm.linear_pool(a2, W4, b4f, bias_after_pool=True, want_rows=False)
+            _, tok, arg2 = gemm.linear_pool(a2, W4, b4f, bias_after_pool=True, want_rows=False, group_rows=K)
         else:
             z = gemm.mm(a2, W4) if adt == torch.bfloat16 else a2 @ W4.t()     # groups of k != 32 points (Point-M2AE level 0: k = 16)
             tok = torch.empty(BGs, C4, dtype=adt, device=dev)

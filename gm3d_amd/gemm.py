@@ -323,14 +323,28 @@ def mm_nn(x, w, out=None):
 POOL_ON_DMA = True        # the pool epilogue on csrc/gemm_dma.hip (128 x 128 / 128 x 192 tiles) instead of csrc/gemm.hip
 
 
-def linear_pool(x, w, bias, bias_after_pool, want_rows):
-    """Conv1d(k=1) over (groups*32, K) rows + max over each group's 32 rows in the GEMM epilogue.
-    -> (rows (M,N) bf16 | None, pooled (M/32,N) bf16, argmax (M/32,N) uint8)."""
+def pool16_supported(x, w):
+    """conv + max over groups of 16 rows in the weight-stationary kernel's epilogue (the hierarchical model's level-0 groups)"""
+    N, K = w.shape
+    return (USE_WS_POOL and ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2
+            and x.shape[0] >= 32768 and x.shape[0] % 16 == 0 and x.shape[1] == K and x.stride(1) == 1 and w.stride(1) == 1
+            and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0
+            and bool(lib.gm3d_gemm_ws_supported(N, K, 1)))
+
+
+def linear_pool(x, w, bias, bias_after_pool, want_rows, group_rows=32):
+    """Conv1d(k=1) over (groups*group_rows, K) rows + max over each group's rows in the GEMM epilogue (group_rows 32; 16 on the
+    weight-stationary kernel only: pool16_supported).
+    -> (rows (M,N) bf16 | None, pooled (M/group_rows,N) bf16, argmax (M/group_rows,N) uint8)."""
     M, K = x.shape
     N = w.shape[0]
     rows = torch.empty(M, N, dtype=torch.bfloat16, device=x.device) if want_rows else None
-    pooled = torch.empty(M // 32, N, dtype=torch.bfloat16, device=x.device)
-    arg = torch.empty(M // 32, N, dtype=torch.uint8, device=x.device)
+    pooled = torch.empty(M // group_rows, N, dtype=torch.bfloat16, device=x.device)
+    arg = torch.empty(M // group_rows, N, dtype=torch.uint8, device=x.device)
+    if group_rows == 16:
+        _launch("gm3d_gemm_tn_bf16_ws_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_poolg, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
+                _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), 16, _stream())
+        return rows, pooled, arg
     if ws_supported(x, w, pool=True):
         _launch("gm3d_gemm_tn_bf16_ws_pool", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_pool, _ptr(x), _ptr(w), _ptr(bias), _ptr(rows),
                 _ptr(pooled), _ptr(arg), M, N, K, x.stride(0), w.stride(0), N, N, int(bias_after_pool), _stream())

@@ -54,12 +54,12 @@ class LinearBiasFn(torch.autograd.Function):
             shp = x.shape
             x2 = x.reshape(-1, shp[-1]).to(adt).contiguous()
             W = weight_cache.get(w, adt).reshape(w.shape[0], -1)
-            if gemm.supported(x2, W):
+            if gemm.supported(x2, W) or gemm.ragged_supported(x2, W):
+                # gemm.mm names the kernel: the tiled families, the ring kernel's ragged last column tile (N = 96), csrc/gemm.hip's
+                # ragged-K form (K = 96), the weight-stationary kernel for the tall ragged shapes
                 y = gemm.mm(x2, W, _c32(b) if b is not None else None)
             elif _ragged_ok(x2, W):
                 y = gemm.linear_tn_ring(x2, W, _c32(b) if b is not None else None)
-            elif gemm.ragged_supported(x2, W):         # ragged K as well (K = 96): csrc/gemm.hip's ragged form
-                y = gemm.linear_tn(x2, W, _c32(b) if b is not None else None)
             else:
                 y = torch.addmm(weight_cache.get(b, adt), x2, W.t()) if b is not None else x2 @ W.t()
             ctx.save_for_backward(x2, w)

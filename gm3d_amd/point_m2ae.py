@@ -285,12 +285,19 @@ class TokenPropagation(nn.Module):
             self.mlp_bns.append(nn.BatchNorm1d(c))
             last = c
 
-    def forward(self, xyz_fine, xyz_coarse, tok_fine, tok_coarse):
-        B, N, _ = xyz_fine.shape
+    @staticmethod
+    def neighbours(xyz_fine, xyz_coarse):
+        """-> (idx (B,N,3) int64, w (B,N,3) f32): the three nearest coarse centres of every fine centre and their normalised
+        inverse-squared-distance weights.  A function of the grouping alone: teacher and student of one step share it."""
         with torch.no_grad():
             dist, idx = ops.knn(xyz_coarse, xyz_fine, 3)                   # (B,N,3): Euclidean distances, ascending
             w = 1.0 / (dist * dist + 1e-8)
             w = w / w.sum(dim=-1, keepdim=True)
+        return idx, w
+
+    def forward(self, xyz_fine, xyz_coarse, tok_fine, tok_coarse, nbrs=None):
+        B, N, _ = xyz_fine.shape
+        idx, w = nbrs if nbrs is not None else self.neighbours(xyz_fine, xyz_coarse)
         from . import heads
         if FUSED_PROPAGATION and tok_fine.is_cuda and tok_fine.dtype in ops._DT and tok_fine.shape[-1] % 8 == 0 and tok_coarse.shape[-1] % 8 == 0:
             y = heads.Interp3Fn.apply(tok_fine, tok_coarse, idx, w).reshape(B * N, -1)       # interpolation + concatenation: one launch
@@ -413,7 +420,7 @@ class PointM2AE(nn.Module):
             prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
         return outs
 
-    def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None):
+    def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None, prop=None):
         """pts (B,N,3) f32; mask (B,64) bool over the COARSEST tokens (True = masked; None: nothing masked).
         vis_count: the number of visible coarsest tokens of EVERY cloud when the caller knows it (generate_mask_ids keeps exactly
         len_keep): a static bound for the visible-first order; a wrong bound sets masked_stack.overflow_flag.
@@ -452,7 +459,7 @@ class PointM2AE(nn.Module):
             loss_pred = F.linear(y, h[3].weight.squeeze(-1), h[3].bias).mean(dim=-1).view(B, self.num_group)
         x1 = self.encoder_norms[1](enc[1])
         x1 = torch.where(vis1.unsqueeze(-1), x1, torch.zeros((), dtype=x1.dtype, device=x1.device))
-        x1 = self.token_prop[0](centers[1], centers[2], x1, xc)
+        x1 = self.token_prop[0](centers[1], centers[2], x1, xc, nbrs=prop)
         x1 = self.h_decoder[1](x1, _pos(self.decoder_pos_embeds[1], centers[1]).to(x1.dtype))
         x1 = self.decoder_norm(x1)
         G1, k1 = neighborhoods[1].shape[1], neighborhoods[1].shape[2]
@@ -482,11 +489,12 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
     raw = model.module if hasattr(model, "module") else model
     with torch.no_grad():
         group = group if group is not None else teacher.group_divider(pts)
-        t = teacher(pts, mask=None, group=group)
+        prop = TokenPropagation.neighbours(group[1][1], group[1][2])     # shared by the teacher's and the student's up-block
+        t = teacher(pts, mask=None, group=group, prop=prop)
         mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
                                                       total_epoch=total_epoch, noise=mask_noise)
         masked = mask.to(torch.bool)
-    out = model(pts, mask=masked, group=group, vis_count=vis_ids.shape[1])
+    out = model(pts, mask=masked, group=group, vis_count=vis_ids.shape[1], prop=prop)
     lo = raw.forward_loss(out["rec"], group[0], group[2], out["masks"])
     pred = M.take(out["loss_pred"].float(), mask_ids)
     target = M.take(lo["matrix"].detach().float(), mask_ids)

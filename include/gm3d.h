@@ -439,6 +439,12 @@ int gm3d_gemm_tn_bf16_ws(const void *A, const void *W, const float *bias, void *
 /* ... with the max-pool epilogue of gm3d_gemm_tn_bf16_pool (one 32-row tile = one group of 32 points): 128 -> 256 and 512 -> 384. */
 int gm3d_gemm_tn_bf16_ws_pool(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N, int K,
                               int lda, int ldw, int ldc, int ldp, int bias_after_pool, gm3d_stream_t stream);
+/* ... for groups of group_rows = 16 or 32 rows (Point-M2AE's level-0 groups hold 16 points, Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:60:
+ * a 32-row tile is then two groups): P / arg (M / group_rows, N), arg counts within its group.  Also 512 -> 96 (that level's token width).
+ * The weight-stationary kernel also takes ragged K (multiples of 8: 96, 192, 288 against N = 96 / 192 / 288 / 384 / 512) for the
+ * hierarchical model's tall products; gm3d_gemm_ws_supported lists every (N, K). */
+int gm3d_gemm_tn_bf16_ws_poolg(const void *A, const void *W, const float *bias, void *C, void *P, unsigned char *arg, int M, int N, int K,
+                               int lda, int ldw, int ldc, int ldp, int bias_after_pool, int group_rows, gm3d_stream_t stream);
 int gm3d_gemm_ws_supported(int N, int K, int pool);
 /* second_conv.0 (256 -> 512 on the local half of the split concat, models_mae_learn_loss.py:880) together with the BatchNorm1d(512)
  * + ReLU behind it (:881), T (M / 32, N) bf16 being the per-group term (global feature @ W_g^T + bias), M % 32 == 0:

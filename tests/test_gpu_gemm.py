@@ -369,6 +369,33 @@ def test_gemm_weight_stationary_pool_epilogue(groups, K, N, after, rows):
     assert torch.equal(pooled, want) and torch.equal(arg, warg)
 
 
+@pytest.mark.parametrize("groups,K,N,after,rows", [(65536, 128, 256, False, True), (65536, 512, 96, True, False), (4099, 128, 256, False, True),
+                                                   (2051, 512, 96, True, False), (2049, 512, 96, False, True)])
+def test_gemm_weight_stationary_pool_epilogue_groups_of_16(groups, K, N, after, rows):
+    """the same epilogue for groups of 16 rows (two groups per 32-row tile: the hierarchical model's level-0 groups of 16 points,
+    Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:60) == the product followed by gm3d_group_max_fwd with K = 16, bit for bit,
+    including an odd number of groups (the last tile holds one group)."""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    M = groups * 16
+    g = torch.Generator(device="cuda").manual_seed(groups + K)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    x[16:32] = x[0:16]                       # exact ties between rows of different groups must not leak across the group border
+    x[5] = x[3]                              # ... and a tie inside a group goes to the earlier row
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    b = torch.randn(N, device="cuda", generator=g) * 0.2
+    full, pooled, arg = gemm.linear_pool(x, w, b, bias_after_pool=after, want_rows=rows, group_rows=16)
+    z = gemm.linear_tn(x, w, None if after else b)
+    if rows:
+        assert torch.equal(full, z)
+    want = torch.empty(groups, N, device="cuda", dtype=torch.bfloat16)
+    warg = torch.empty(groups, N, device="cuda", dtype=torch.uint8)
+    check(lib.gm3d_group_max_fwd(_ptr(z), _ptr(b) if after else None, _ptr(want), _ptr(warg), groups, 16, N, 1, _stream()), "gmax")
+    assert torch.equal(pooled, want) and torch.equal(arg, warg)
+    assert int(arg.max()) <= 15
+
+
 @pytest.mark.parametrize("groups", [2048, 8192, 1031])
 def test_gemm_weight_stationary_batchnorm_epilogues(groups):
     """second_conv.0 (256 -> 512) with the BatchNorm behind it inside the product's launch (csrc/gemm_ws.hip EPI 4 / 5):
