@@ -61,6 +61,7 @@ SIGNATURES = {
     "gm3d_bn_bcast_bwd_apply_sel": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_lin3_gelu_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_lin3_gelu_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp],
+    "gm3d_lin3_finish": [_vp, _i, _i, _vp, _vp, _vp],
     "gm3d_rank_loss": [_vp, _vp, _i, _i, _vp, _vp, _vp],
     "gm3d_rank_loss_tail": [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "gm3d_rank_loss_tail_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp],
@@ -104,6 +105,7 @@ SIGNATURES = {
                           ctypes.c_longlong, _vp],
     "gm3d_gemm_nt_splits": [_i, _i, _i, _i],
     "gm3d_radius_mask_bits": [_vp, _vp, _f, _i, _i, _vp, _vp],
+    "gm3d_radius_mask_bits_m": [_vp, _vp, _i, _f, _i, _i, _vp, _vp],
     "gm3d_attention_masked_set_wide": [_i],
     "gm3d_attention_masked_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_masked_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
@@ -129,6 +131,8 @@ SIGNATURES = {
     "gm3d_back_project": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "gm3d_interp3_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gather_rows_bwd_w": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "gm3d_where_rows": [_vp, _i, _vp, _vp, _i, _vp, ctypes.c_longlong, _i, _i, _vp],
+    "gm3d_take_rows": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "gm3d_colsum_partial_w": [_vp, _vp, _i, _i, _vp, _i, _vp],
     "gm3d_gemm_tn_bf16_dma_pool": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dmaw": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

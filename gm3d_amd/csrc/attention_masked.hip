@@ -444,7 +444,7 @@ __global__ __launch_bounds__(128) void mattn_bwd_f32_kernel(const float* __restr
 // grid (ceil(G W / 256), B): one thread per (i, word) of cloud blockIdx.y, the cloud's centres and visibility staged in LDS (the 32
 // partners of a word were 32 dependent global loads per thread: 110 us at B = 128, G = 512).
 __global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __restrict__ center, const unsigned char* __restrict__ vis,
-                                                               float radius, int B, int G, int W, unsigned* __restrict__ bits) {
+                                                               float radius, int B, int G, int W, unsigned* __restrict__ bits, int inv) {
     extern __shared__ float rsm[];               // x[G] | y[G] | z[G] | vis[G] (as float flags)
     float* cx = rsm;
     float* cy = cx + G;
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void radius_mask_bits_kernel(const float* __re
     const float* c = center + (size_t)b * G * 3;
     for (int j = threadIdx.x; j < G; j += 256) {
         cx[j] = c[3 * j]; cy[j] = c[3 * j + 1]; cz[j] = c[3 * j + 2];
-        cv[j] = (!vis || vis[(size_t)b * G + j]) ? 1.f : 0.f;
+        cv[j] = (!vis || ((vis[(size_t)b * G + j] != 0) != (inv != 0))) ? 1.f : 0.f;      // inv: the flags say "masked"
     }
     __syncthreads();
     const int id = blockIdx.x * 256 + threadIdx.x;
@@ -502,13 +502,20 @@ extern "C" int gm3d_attention_masked_set_wide(int on) {
 
 extern "C" int gm3d_radius_mask_bits(const float* center, const unsigned char* vis, float radius, int B, int G, unsigned* bits,
                                      gm3d_stream_t stream) {
+    return gm3d_radius_mask_bits_m(center, vis, 0, radius, B, G, bits, stream);
+}
+
+extern "C" int gm3d_radius_mask_bits_m(const float* center, const unsigned char* flags, int flags_are_masked, float radius, int B, int G,
+                                       unsigned* bits, gm3d_stream_t stream) {
     using namespace gm3d;
+    const unsigned char* vis = flags;
+    const int inv = flags_are_masked ? 1 : 0;
     if (!center || !bits || B < 0 || G < 1) return GM3D_EINVAL;
     if (B == 0) return GM3D_OK;
     const int W = (G + 31) / 32;
     if (G > 8192 || B > 65535) return GM3D_EUNSUPPORTED;
     hipLaunchKernelGGL(radius_mask_bits_kernel, dim3((unsigned)((G * W + 255) / 256), (unsigned)B), dim3(256), (size_t)4 * G * sizeof(float),
-                       (hipStream_t)stream, center, vis, radius, B, G, W, bits);
+                       (hipStream_t)stream, center, vis, radius, B, G, W, bits, inv);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

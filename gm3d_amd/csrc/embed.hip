@@ -380,8 +380,12 @@ __global__ __launch_bounds__(256) void pn_layer1_bwd_stats_kernel(const T* __res
     }
 }
 
+// LIN3: the finish of gm3d_lin3_gelu_bwd's partial sums written where the layer's gradients live: columns [0, C) -> db (C) f32, columns
+// [(1 + k) C, (2 + k) C) -> dW (C, 3) f32 column k (the same f64 sums, cast once: what .float() of the f64 result gave)
+template <bool LIN3>
 __global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __restrict__ partial, int nrows, int pitch,
-                                                                int ncols, double* __restrict__ out) {
+                                                                int ncols, double* __restrict__ out, float* __restrict__ dW,
+                                                                float* __restrict__ db, int C) {
     __shared__ double red[8][32];
     const int cx = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cx;
@@ -402,7 +406,13 @@ __global__ __launch_bounds__(256) void colsum_finish_f64_kernel(const double* __
         double t = 0.0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) t += red[k][cx];
-        out[c] = t;
+        if (LIN3) {
+            const int which = c / C, cc = c - which * C;
+            if (which == 0) db[cc] = (float)t;
+            else dW[cc * 3 + which - 1] = (float)t;
+        } else {
+            out[c] = t;
+        }
     }
 }
 
@@ -1208,8 +1218,17 @@ extern "C" int gm3d_colsum_finish_f64(const double* partial, int nrows, int pitc
                                       gm3d_stream_t stream) {
     using namespace gm3d;
     if (!partial || !out || nrows < 0 || ncols < 1 || pitch < ncols) return GM3D_EINVAL;
-    hipLaunchKernelGGL(colsum_finish_f64_kernel, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows,
-                       pitch, ncols, out);
+    hipLaunchKernelGGL(colsum_finish_f64_kernel<false>, dim3((ncols + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows,
+                       pitch, ncols, out, nullptr, nullptr, 1);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_lin3_finish(const double* partial, int nrows, int C, float* dW, float* db, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!partial || !dW || !db || nrows < 0 || C < 1) return GM3D_EINVAL;
+    hipLaunchKernelGGL(colsum_finish_f64_kernel<true>, dim3((4 * C + 31) / 32), dim3(256), 0, (hipStream_t)stream, partial, nrows, 4 * C,
+                       4 * C, nullptr, dW, db, C);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -348,3 +348,85 @@ extern "C" int gm3d_back_project(const unsigned char* masked_c, const long long*
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }
+
+// ===================================================================== row-wise choice by a per-token flag, gather by int64 lists
+// out[b][t][:] = flag[b][t] ? alt[b][t][:] : a[b][t][:]   (flag (B,T) bytes; alt NULL: zeros; alt_bcast != 0: alt is ONE row (C) for every
+// token -- the mask token).  The hierarchical model's "a masked token keeps / takes ..." sites (gm3d_amd/point_m2ae.py: the un-encoded
+// embedding handed to the next level, the mask token of the decoder, the zeroed invisible rows) and their backward (flag inverted by
+// `invert`): one launch instead of bitwise_not + where (+ zeros).
+namespace gm3d {
+
+template <class V>
+__global__ __launch_bounds__(256) void where_rows_kernel(const unsigned char* __restrict__ flag, int invert, const V* __restrict__ a,
+                                                         const V* __restrict__ alt, int alt_bcast, V* __restrict__ out, int cpr, long long total) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long row = g / cpr;
+        const int c = (int)(g - row * cpr);
+        const bool f = (flag[row] != 0) != (invert != 0);
+        V v;
+        if (!f) v = a ? a[g] : V{};
+        else if (alt) v = alt[alt_bcast ? (size_t)c : (size_t)g];
+        else v = V{};
+        out[g] = v;
+    }
+}
+
+// out (B,J,C) = a[b][idx[b][j]][:] for int64 idx (B,J) that may repeat a source row (the member lists of the grouping)
+template <class V>
+__global__ __launch_bounds__(256) void take_rows_kernel(const V* __restrict__ a, const long long* __restrict__ idx, V* __restrict__ out, int S,
+                                                        int J, int cpr, long long total) {
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < total; g += (long long)gridDim.x * 256) {
+        const long long row = g / cpr;                // b * J + j
+        const int c = (int)(g - row * cpr);
+        const int b = (int)(row / J);
+        out[g] = a[((size_t)b * S + (int)idx[row]) * cpr + c];
+    }
+}
+
+}  // namespace gm3d
+
+extern "C" int gm3d_where_rows(const unsigned char* flag, int invert, const void* a, const void* alt, int alt_bcast, void* out, long long rows,
+                               int C, int elem_bytes, gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!flag || !out || rows < 0 || C < 1 || (elem_bytes != 2 && elem_bytes != 4) || (alt_bcast && !alt)) return GM3D_EINVAL;
+    if (rows == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long row_bytes = (long long)C * elem_bytes;
+    const bool wide = row_bytes % 16 == 0 && ((uintptr_t)out % 16 == 0) && (!a || (uintptr_t)a % 16 == 0) && (!alt || (uintptr_t)alt % 16 == 0);
+    const int cpr = wide ? (int)(row_bytes / 16) : C;
+    const long long total = rows * cpr;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (wide)
+        hipLaunchKernelGGL(where_rows_kernel<uint4>, dim3(grid), dim3(256), 0, st, flag, invert, (const uint4*)a, (const uint4*)alt, alt_bcast,
+                           (uint4*)out, cpr, total);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(where_rows_kernel<unsigned>, dim3(grid), dim3(256), 0, st, flag, invert, (const unsigned*)a, (const unsigned*)alt,
+                           alt_bcast, (unsigned*)out, cpr, total);
+    else
+        hipLaunchKernelGGL(where_rows_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, flag, invert, (const unsigned short*)a,
+                           (const unsigned short*)alt, alt_bcast, (unsigned short*)out, cpr, total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}
+
+extern "C" int gm3d_take_rows(const void* a, const long long* idx, void* out, int B, int S, int J, int C, int elem_bytes,
+                              gm3d_stream_t stream) {
+    using namespace gm3d;
+    if (!a || !idx || !out || B < 0 || S < 1 || J < 1 || C < 1 || (elem_bytes != 2 && elem_bytes != 4)) return GM3D_EINVAL;
+    if (B == 0) return GM3D_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long row_bytes = (long long)C * elem_bytes;
+    const bool wide = row_bytes % 16 == 0 && ((uintptr_t)a % 16 == 0) && ((uintptr_t)out % 16 == 0);
+    const int cpr = wide ? (int)(row_bytes / 16) : C;
+    const long long total = (long long)B * J * cpr;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    if (wide)
+        hipLaunchKernelGGL(take_rows_kernel<uint4>, dim3(grid), dim3(256), 0, st, (const uint4*)a, idx, (uint4*)out, S, J, cpr, total);
+    else if (elem_bytes == 4)
+        hipLaunchKernelGGL(take_rows_kernel<unsigned>, dim3(grid), dim3(256), 0, st, (const unsigned*)a, idx, (unsigned*)out, S, J, cpr, total);
+    else
+        hipLaunchKernelGGL(take_rows_kernel<unsigned short>, dim3(grid), dim3(256), 0, st, (const unsigned short*)a, idx, (unsigned short*)out,
+                           S, J, cpr, total);
+    GM3D_CHECK_LAUNCH();
+    return GM3D_OK;
+}

@@ -282,8 +282,15 @@ _ASYNC_WGRAD = {"stream": None, "used": False, "min_blocks": 5, "deferred": []}
 def _wgrad_many(reqs):
     """[(dy, x, out slot | None), ...] -> [dW, ...]: one launch for all of them where the NT kernel takes every request
     (gemm.wgrad_nt_multi), else one batched GEMM per request."""
-    if gemm.MULTI_WGRAD and 1 < len(reqs) <= 16 and all(gemm.wgrad_multi_ok(dy, x, out) for dy, x, out in reqs):
-        return gemm.wgrad_nt_multi(reqs)
+    if gemm.MULTI_WGRAD and len(reqs) > 1 and all(gemm.wgrad_multi_ok(dy, x, out) for dy, x, out in reqs):
+        if len(reqs) <= 16:
+            return gemm.wgrad_nt_multi(reqs)
+        res = []                      # the kernel takes 16 problems per launch: ceil(n / 16) launches of about equal size
+        per = -(-len(reqs) // -(-len(reqs) // 16))
+        for i in range(0, len(reqs), per):
+            chunk = reqs[i:i + per]
+            res += gemm.wgrad_nt_multi(chunk) if len(chunk) > 1 else [_wgrad_batched(*chunk[0])]
+        return res
     return [_wgrad_batched(dy, x, out) for dy, x, out in reqs]
 
 
@@ -293,7 +300,8 @@ def defer_wgrad(dy, x, w=None):
     read or add to the result before the region ends), the product joins the stacks' one-launch weight gradients and lands in the slot;
     elsewhere, or when the kernel does not take the shape, it is computed now."""
     reg = _ASYNC_WGRAD
-    if (reg["stream"] is not None and gemm.MULTI_WGRAD and DEFER_HEAD_WGRAD and w is not None and w.grad is None and dy.dim() == 2
+    if (reg["stream"] is not None and gemm.MULTI_WGRAD and (DEFER_HEAD_WGRAD or reg.get("defer_heads")) and w is not None and w.grad is None
+            and dy.dim() == 2
             and dy.is_contiguous() and x.is_contiguous()):
         from .optim import grad_slots, ENABLE_DIRECT_WGRAD
         slot = grad_slots.get(w) if ENABLE_DIRECT_WGRAD else None
@@ -330,21 +338,25 @@ class async_wgrad:
     """with async_wgrad(device): <backward>  -- weight-gradient GEMMs of the deep block stacks run on a side stream during the
     region; on exit the current stream waits for it (so whatever follows -- gradient gather, all-reduce, optimizer -- sees them)."""
 
-    def __init__(self, device, min_blocks=None):
+    def __init__(self, device, min_blocks=None, defer_heads=False):
+        """defer_heads: weight gradients of layers outside the block stacks (fused.defer_wgrad: token embeds, heads, positional MLPs)
+        join ONE launch at the region's exit -- for a model with many small such layers (Point-M2AE: 19) that is 2 launches instead
+        of 38; for the north-star model's three it measured slower (DEFER_HEAD_WGRAD)."""
         self.dev, self.min_blocks = torch.device(device), (WGRAD_MIN_BLOCKS if min_blocks is None else min_blocks)
+        self.defer_heads = bool(defer_heads)
 
     def __enter__(self):
         if ASYNC_WGRAD and self.dev.type == "cuda":
             key = (self.dev.type, self.dev.index)
             if key not in _wgrad_streams:
                 _wgrad_streams[key] = torch.cuda.Stream(device=self.dev)
-            _ASYNC_WGRAD.update(stream=_wgrad_streams[key], used=False, min_blocks=self.min_blocks)
+            _ASYNC_WGRAD.update(stream=_wgrad_streams[key], used=False, min_blocks=self.min_blocks, defer_heads=self.defer_heads)
         return self
 
     def __exit__(self, *exc):
         reg = _ASYNC_WGRAD
         ws, used = reg["stream"], reg["used"]
-        reg.update(stream=None, used=False)
+        reg.update(stream=None, used=False, defer_heads=False)
         if reg["deferred"]:                 # no deep stack came by to take them along: run them here, in line
             if exc[0] is None:
                 _run_deferred(reg)

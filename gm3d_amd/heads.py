@@ -196,6 +196,12 @@ class TakeRowsFn(torch.autograd.Function):
         ids = ids.contiguous()
         ctx.save_for_backward(ids)
         ctx.S, ctx.xdt = S, x.dtype
+        if x.element_size() in (2, 4):
+            x = x.contiguous()
+            out = torch.empty(B, ids.shape[1], C, dtype=x.dtype, device=x.device)
+            _launch("gm3d_take_rows", {"B": B, "J": ids.shape[1], "C": C}, lib.gm3d_take_rows, _ptr(x), _ptr(ids), _ptr(out), B, S,
+                    ids.shape[1], C, x.element_size(), _stream())
+            return out
         return torch.gather(x, 1, ids.unsqueeze(-1).expand(-1, -1, C))
 
     @staticmethod
@@ -278,6 +284,56 @@ class Interp3Fn(torch.autograd.Function):
         _launch("gm3d_gather_rows_bwd", {"B": B, "J": J, "S": S, "C": C2, "dtype": str(dout.dtype)}, lib.gm3d_gather_rows_bwd_w, _ptr(dout),
                 C1 + C2, C1, 3, _ptr(w), _ptr(off), _ptr(lst), _ptr(dcoarse), B, J, S, C2, _DT[dout.dtype], _stream())
         return dout[..., :C1], dcoarse, None, None
+
+
+class WhereRowsFn(torch.autograd.Function):
+    """out[b][t] = masked[b][t] ? alt[b][t] : a[b][t]  (a (B,T,C); alt (B,T,C), a single row (1,1,C) / (C,) -- the mask token --, or None
+    = zeros; masked (B,T) bool): the hierarchical model's per-token choices as one launch forward and one per input backward
+    (csrc/gather.hip gm3d_where_rows).  A broadcast alt's gradient is a column sum over the masked rows (our two-stage kernel)."""
+
+    @staticmethod
+    def forward(ctx, masked, a, alt):
+        B, T, C = a.shape
+        a = a.contiguous()
+        m = masked.contiguous()
+        m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+        bcast = alt is not None and alt.numel() == C
+        altc = None
+        if alt is not None:
+            altc = (weight_cache.get(alt, a.dtype) if bcast else alt.to(a.dtype)).contiguous()
+        out = torch.empty_like(a)
+        _launch("gm3d_where_rows", {"rows": B * T, "C": C}, lib.gm3d_where_rows, _ptr(m), 0, _ptr(a), _ptr(altc), int(bcast), _ptr(out), B * T, C,
+                a.element_size(), _stream())
+        ctx.save_for_backward(m)
+        ctx.info = (B, T, C, bcast, alt.dtype if alt is not None else None, alt.shape if alt is not None else None, a.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (m,) = ctx.saved_tensors
+        B, T, C, bcast, altdt, altshape, adt = ctx.info
+        dout = dout.contiguous()
+        da = dalt = None
+        if ctx.needs_input_grad[1]:
+            da = torch.empty_like(dout)
+            _launch("gm3d_where_rows", {"rows": B * T, "C": C}, lib.gm3d_where_rows, _ptr(m), 0, _ptr(dout), None, 0, _ptr(da), B * T, C,
+                    dout.element_size(), _stream())
+        if altshape is not None and ctx.needs_input_grad[2]:
+            dm = torch.empty_like(dout)
+            _launch("gm3d_where_rows", {"rows": B * T, "C": C}, lib.gm3d_where_rows, _ptr(m), 1, _ptr(dout), None, 0, _ptr(dm), B * T, C,
+                    dout.element_size(), _stream())
+            dalt = colsum(dm.view(B * T, C), dm.dtype).view(altshape).to(altdt) if bcast else dm.to(altdt)
+        return None, da, dalt
+
+
+def where_rows(masked, a, alt=None):
+    """masked ? alt : a per token, one launch (GPU, 2- or 4-byte elements); torch.where elsewhere."""
+    if a.is_cuda and a.dim() == 3 and a.element_size() in (2, 4) and masked.shape == a.shape[:2]:
+        return WhereRowsFn.apply(masked, a, alt)
+    m = masked.unsqueeze(-1)
+    if alt is None:
+        return torch.where(m, torch.zeros((), dtype=a.dtype, device=a.device), a)
+    return torch.where(m, alt.to(a.dtype).reshape(1, 1, -1) if alt.numel() == a.shape[-1] else alt.to(a.dtype), a)
 
 
 def take_rows(x, ids):
@@ -394,8 +450,11 @@ class PosEmbedFn(torch.autograd.Function):
             part = torch.empty(nrows, 4 * C, dtype=torch.float64, device=x.device)
             _launch("gm3d_lin3_gelu_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_lin3_gelu_bwd, _ptr(dh), _ptr(x),
                     _ptr(w0f), _ptr(b0f), R, C, _ptr(part), _DT[adt], _stream())
-            q = _finish64(part, nrows, 4 * C).view(4, C)
-            return None, q[1:4].t().float().contiguous(), q[0].float(), dW1, db1, None
+            dW0 = torch.empty(C, 3, dtype=torch.float32, device=x.device)
+            db0 = torch.empty(C, dtype=torch.float32, device=x.device)
+            _launch("gm3d_colsum_finish_f64", {"rows": nrows, "cols": 4 * C}, lib.gm3d_lin3_finish, _ptr(part), nrows, C, _ptr(dW0), _ptr(db0),
+                    _stream())
+            return None, dW0, db0, dW1, db1, None
 
 
 class LossPredHeadFn(torch.autograd.Function):
@@ -571,7 +630,7 @@ class ExpandRowsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, token, B, N, dtype):
         ctx.tdt = token.dtype
-        return token.to(dtype).expand(B, N, -1)
+        return weight_cache.get(token, dtype).expand(B, N, -1)      # (the optimizer's shadow where there is one: no cast launch)
 
     @staticmethod
     def backward(ctx, g):

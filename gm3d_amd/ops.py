@@ -327,16 +327,26 @@ def pack_mask(mask):
     return torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32).contiguous()
 
 
-def radius_mask_bits(center, vis, radius):
+def radius_mask_bits(center, vis, radius, masked=None):
     """center (B,G,3) f32, vis (B,G) bool | None -> (B,G,ceil(G/32)) int32 bitset: pair (i,j) blocked iff i or j invisible or their
-    centres are >= radius apart (== pack_mask(~(vis_i & vis_j) | dist2 >= radius^2), in one launch and without the (B,G,G) tensors)."""
+    centres are >= radius apart (== pack_mask(~(vis_i & vis_j) | dist2 >= radius^2), in one launch and without the (B,G,G) tensors).
+    masked (B,G) bool (True = NOT visible) may be given instead of vis (no bitwise_not, no converting copy)."""
     center = center.detach().contiguous()
     _require(center, torch.float32, "center")
     B, G, _ = center.shape
-    v = vis.to(torch.uint8).contiguous() if vis is not None else None
+    inv = 0
+    if masked is not None and vis is None:
+        v = masked.contiguous()
+        v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+        inv = 1
+    elif vis is not None:
+        v = vis.contiguous()
+        v = v.view(torch.uint8) if v.dtype == torch.bool else v.to(torch.uint8)
+    else:
+        v = None
     bits = torch.empty(B, G, (G + 31) // 32, dtype=torch.int32, device=center.device)
-    _launch("gm3d_radius_mask_bits", {"B": B, "G": G}, lib.gm3d_radius_mask_bits, _ptr(center), _ptr(v), float(radius), B, G, _ptr(bits),
-            _stream())
+    _launch("gm3d_radius_mask_bits", {"B": B, "G": G}, lib.gm3d_radius_mask_bits_m, _ptr(center), _ptr(v), inv, float(radius), B, G,
+            _ptr(bits), _stream())
     return bits
 
 

@@ -46,6 +46,7 @@ POOL_TAPS = None          # tests set this to a list: every max-pool of a grad-e
 #                           (tests/test_gpu_m2ae.py)
 FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
 FUSED_PROPAGATION = True  # token propagation: 3-NN interpolation + concatenation as one launch (heads.Interp3Fn), deterministic backward
+DEFER_WGRADS = True       # pretrain_step: weight gradients of the layers outside the block stacks as one launch at the end of backward
 STACK_NODE = True         # a block stack as ONE autograd node (masked_stack.MaskedStackFn): the weight gradients of all its blocks in one
 #                           launch, one column-sum finish per kind, one transposing launch; FUSED_BLOCKS' per-op nodes are the cross-check
 VISIBLE_FIRST = True      # student pass: every level's stack runs on the visible tokens moved to the front of the cloud, cut to the
@@ -411,13 +412,13 @@ class PointM2AE(nn.Module):
                 prev = S.MergeFn.apply(y_c, tok, part)            # a masked token hands on its un-encoded embedding
                 outs.append(prev)
                 continue
-            vis = ~masks[i]
+            from . import heads
             with torch.no_grad():       # == pack_mask(~(vis_i & vis_j) | radius_mask(centres)), one launch
-                bits = ops.radius_mask_bits(centers[i], vis, self.local_radius[i])
+                bits = ops.radius_mask_bits(centers[i], None, self.local_radius[i], masked=masks[i])
             pos = _pos(self.encoder_pos_embeds[i], centers[i])
             y = self.encoder_blocks[i](tok, pos.to(tok.dtype), bits)
             outs.append(y)
-            prev = torch.where(vis.unsqueeze(-1), y, tok)         # a masked token hands on its un-encoded embedding
+            prev = heads.where_rows(masks[i], y, tok)              # a masked token hands on its un-encoded embedding
         return outs
 
     def forward(self, pts, mask=None, group=None, noaug=False, vis_count=None, prop=None):
@@ -432,16 +433,12 @@ class PointM2AE(nn.Module):
             mask = torch.zeros(B, self.num_group, dtype=torch.bool, device=centers[0].device)
         masks = back_project(mask, idxs)
         enc = self.encode(neighborhoods, centers, idxs, masks, vis_count=vis_count, compact=compact)
-        vis2, vis1 = ~masks[2], ~masks[1]
         x2 = self.encoder_norms[2](enc[2])
         if noaug:
             return x2
-        if x2.is_cuda:       # the token's gradient = a column sum over B*64 rows: our own kernel (replay-safe), not torch's reduction
-            from . import heads
-            mtok = heads.ExpandRowsFn.apply(self.mask_token, B, self.num_group, x2.dtype)
-        else:
-            mtok = self.mask_token.to(x2.dtype).expand(B, self.num_group, -1)
-        xc = torch.where(vis2.unsqueeze(-1), x2, mtok)
+        from . import heads
+        # the mask token's gradient = a column sum over the masked rows: our own kernel (replay-safe), not torch's reduction
+        xc = heads.where_rows(masks[2], x2, self.mask_token)
         xc = self.h_decoder[0](xc, _pos(self.decoder_pos_embeds[0], centers[2]).to(xc.dtype))
         h = self.loss_pred_head
         if xc.is_cuda:
@@ -458,7 +455,7 @@ class PointM2AE(nn.Module):
             y = F.leaky_relu(h[1](F.linear(xc.reshape(B * self.num_group, -1), h[0].weight.squeeze(-1), h[0].bias)), h[2].negative_slope)
             loss_pred = F.linear(y, h[3].weight.squeeze(-1), h[3].bias).mean(dim=-1).view(B, self.num_group)
         x1 = self.encoder_norms[1](enc[1])
-        x1 = torch.where(vis1.unsqueeze(-1), x1, torch.zeros((), dtype=x1.dtype, device=x1.device))
+        x1 = heads.where_rows(masks[1], x1, None)
         x1 = self.token_prop[0](centers[1], centers[2], x1, xc, nbrs=prop)
         x1 = self.h_decoder[1](x1, _pos(self.decoder_pos_embeds[1], centers[1]).to(x1.dtype))
         x1 = self.decoder_norm(x1)
@@ -515,6 +512,11 @@ def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None
     with amp:
         out = pretrain_forward(model, model_ema.ema, pts, epoch, args.epochs, mask_noise=mask_noise)
     optimizer.zero_grad(set_to_none=True)
-    out["loss"].backward()
+    if DEFER_WGRADS and pts.is_cuda:
+        from . import fused
+        with fused.async_wgrad(pts.device, defer_heads=True):       # the 19 small layers' weight gradients: one launch at the exit
+            out["loss"].backward()
+    else:
+        out["loss"].backward()
     out["grad_norm"] = E.step_update(model, model_ema, optimizer)
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}

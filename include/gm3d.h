@@ -310,6 +310,9 @@ int gm3d_lin3_gelu_fwd(const float *x, const float *w, const float *b, void *out
  * rows = gm3d_embed_partial_rows(3, R, C); C <= 512. */
 int gm3d_lin3_gelu_bwd(const void *dout, const float *x, const float *w, const float *b, int R, int C,
                        double *partial, int dtype, gm3d_stream_t stream);
+/* The finish of its partial sums in the layer's own layouts: db (C) f32 = the column sums of block 0, dW (C,3) f32 column k = block 1 + k
+ * (partial (nrows, 4 C) f64, the buffer gm3d_lin3_gelu_bwd filled). */
+int gm3d_lin3_finish(const double *partial, int nrows, int C, float *dW, float *db, gm3d_stream_t stream);
 
 /* Pairwise ranking loss of forward_learning_loss(relative=True) (models_mae_learn_loss.py:795-805), per sample:
  * out (B,2) f32 = [sum of pair terms, number of ordered pairs]; dpred (B,M) = d(sum of pair terms)/d pred.  M <= 64. */
@@ -557,6 +560,9 @@ int gm3d_gather_rows_bwd(const void *dy, const int *off, const int *list, void *
  * not visible (vis (B,G) bytes, NULL = all visible) or their centres (B,G,3) are >= radius apart (radius <= 0: no radius test). */
 int gm3d_radius_mask_bits(const float *center, const unsigned char *vis, float radius, int B, int G, unsigned *bits,
                           gm3d_stream_t stream);
+/* ... with the flags' sense selectable: flags_are_masked != 0 -> a non-zero byte means NOT visible (the multi-scale masks as they are) */
+int gm3d_radius_mask_bits_m(const float *center, const unsigned char *flags, int flags_are_masked, float radius, int B, int G,
+                            unsigned *bits, gm3d_stream_t stream);
 /* Visible-first token order of one masked level (the student's pass: multi-scale masking at ratio 0.8,
  * Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:57-99; gm3d_amd/point_m2ae.py).  masked (B,T) bytes (non-zero = masked), T <= 1024,
  * 1 <= Tc <= T (a static bound on the visible count, or T):  perm_c (B,Tc) int32 = token at compact slot j (visible tokens in
@@ -579,6 +585,12 @@ int gm3d_interp3_fwd(const void *coarse, const long long *idx, const float *w, c
                      int C2, int dtype, gm3d_stream_t stream);
 int gm3d_gather_rows_bwd_w(const void *dy, int ldy, int col0, int refs_per_row, const float *w, const int *off, const int *list, void *dx,
                            int B, int J, int S, int C, int dtype, gm3d_stream_t stream);
+/* out[row] = flag[row] (xor invert) ? alt[row] : a[row] over `rows` rows of C elements (elem_bytes 2 / 4); a NULL / alt NULL: zeros;
+ * alt_bcast: alt is one row (C) for every row (the decoder's mask token).  gm3d_amd/point_m2ae.py's per-token choices and their backward. */
+int gm3d_where_rows(const unsigned char *flag, int invert, const void *a, const void *alt, int alt_bcast, void *out, long long rows, int C,
+                    int elem_bytes, gm3d_stream_t stream);
+/* out (B,J,C) = a[b][idx[b][j]] for int64 idx (B,J) with repeats (the forward of the member gathers; backward: gm3d_gather_rows_bwd). */
+int gm3d_take_rows(const void *a, const long long *idx, void *out, int B, int S, int J, int C, int elem_bytes, gm3d_stream_t stream);
 /* out (B,T,C) row by row: idx[b][t] >= 0 -> a[b][idx[b][t]] (a is (B,Ta,C)), else alt[b][t] (alt (B,T,C)) or zeros (alt NULL).
  * elem_bytes 2 or 4.  Gather into / scatter out of the compact order above, forward and backward (indices without repeats). */
 int gm3d_select_rows(const void *a, const int *idx, const void *alt, void *out, int B, int Ta, int T, int C, int elem_bytes,

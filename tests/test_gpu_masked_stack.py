@@ -229,3 +229,39 @@ def test_interp3_and_group_max_nodes(dtype):
     first = (x.detach().float() == vals.unsqueeze(1)).float().argmax(dim=1)
     want = torch.zeros_like(x.detach().float()).scatter_(1, first.unsqueeze(1), 1.0)
     assert torch.equal(x.grad.float(), want)
+
+
+@pytest.mark.parametrize("dtype,C", [(torch.float32, 192), (torch.bfloat16, 96), (torch.float32, 3), (torch.bfloat16, 384)])
+def test_where_rows_and_take_rows_nodes(dtype, C):
+    from gm3d_amd import heads, ops
+    from gm3d_amd.point_m2ae import radius_mask
+    torch.manual_seed(4)
+    B, T = 5, 77
+    masked = torch.rand(B, T, device="cuda") < 0.6
+    a = torch.randn(B, T, C, device="cuda").to(dtype).requires_grad_(True)
+    alt = torch.randn(B, T, C, device="cuda").to(dtype).requires_grad_(True)
+    tok = torch.nn.Parameter(torch.randn(1, 1, C, device="cuda"))
+    w = torch.randn(B, T, C, device="cuda")
+    m3 = masked.unsqueeze(-1)
+    # full alternative
+    out = heads.where_rows(masked, a, alt)
+    (out.float() * w).sum().backward()
+    assert torch.equal(out.detach(), torch.where(m3, alt.detach(), a.detach()))
+    assert torch.equal(a.grad.float(), torch.where(m3, torch.zeros_like(w), w).to(dtype).float())
+    assert torch.equal(alt.grad.float(), torch.where(m3, w, torch.zeros_like(w)).to(dtype).float())
+    # one row for every masked token (the mask token), and zeros
+    a.grad = None
+    out = heads.where_rows(masked, a, tok)
+    (out.float() * w).sum().backward()
+    assert torch.equal(out.detach(), torch.where(m3, tok.detach().to(dtype), a.detach()))
+    want = torch.where(m3, w.to(dtype).float(), torch.zeros_like(w)).double().sum(dim=(0, 1))
+    assert float((tok.grad.double().flatten() - want).abs().max()) <= 1e-5 * float(want.abs().max()) + 1e-6
+    assert torch.equal(heads.where_rows(masked, a.detach(), None), torch.where(m3, torch.zeros_like(a.detach()), a.detach()))
+    # gather by int64 lists with repeats: forward == torch.gather (the backward is csrc/gather.hip's, tested with the model)
+    ids = torch.randint(0, T, (B, 200), device="cuda")
+    got = heads.take_rows(a.detach(), ids) if C % 8 == 0 else None
+    if got is not None:
+        assert torch.equal(got, torch.gather(a.detach(), 1, ids.unsqueeze(-1).expand(-1, -1, C)))
+    # the radius mask from the "masked" flags directly
+    cen = clouds.pc_norm(torch.randn(B, T, 3)).cuda()
+    assert torch.equal(ops.radius_mask_bits(cen, None, 0.5, masked=masked), ops.radius_mask_bits(cen, ~masked, 0.5))
