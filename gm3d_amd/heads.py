@@ -322,7 +322,10 @@ class WhereRowsFn(torch.autograd.Function):
             dm = torch.empty_like(dout)
             _launch("gm3d_where_rows", {"rows": B * T, "C": C}, lib.gm3d_where_rows, _ptr(m), 1, _ptr(dout), None, 0, _ptr(dm), B * T, C,
                     dout.element_size(), _stream())
-            dalt = colsum(dm.view(B * T, C), dm.dtype).view(altshape).to(altdt) if bcast else dm.to(altdt)
+            if bcast:      # (our two-stage column sum takes widths that are multiples of 8: every token width of the model)
+                dalt = (colsum(dm.view(B * T, C), dm.dtype) if C % 8 == 0 else dm.float().sum(dim=(0, 1))).view(altshape).to(altdt)
+            else:
+                dalt = dm.to(altdt)
         return None, da, dalt
 
 
