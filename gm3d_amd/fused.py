@@ -63,6 +63,7 @@ class _WeightCache:
     def pin_view(self, p, shadow):
         """Register an externally maintained bf16 copy of `p` (FlatAdamWEma rewrites it inside its update kernel)."""
         self._pinned[p.data_ptr()] = (shadow, weakref.ref(p))
+        gemm.forget_transposes()        # shadows of another optimizer: whatever mm_nn remembered is stale
 
     def _is_pinned(self, p):
         hit = self._pinned.get(p.data_ptr())
@@ -351,11 +352,15 @@ class async_wgrad:
             if key not in _wgrad_streams:
                 _wgrad_streams[key] = torch.cuda.Stream(device=self.dev)
             _ASYNC_WGRAD.update(stream=_wgrad_streams[key], used=False, min_blocks=self.min_blocks, defer_heads=self.defer_heads)
+            if self.defer_heads:
+                gemm.prepare_transposes()       # the small layers' transposed weight shadows: one launch per eight, not one per layer
         return self
 
     def __exit__(self, *exc):
         reg = _ASYNC_WGRAD
         ws, used = reg["stream"], reg["used"]
+        if reg.get("defer_heads"):
+            gemm.drop_transposes()
         reg.update(stream=None, used=False, defer_heads=False)
         if reg["deferred"]:                 # no deep stack came by to take them along: run them here, in line
             if exc[0] is None:

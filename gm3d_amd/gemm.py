@@ -307,13 +307,57 @@ def transposed(w):
     return w.t().contiguous()
 
 
+# Transposed shadows of the weights mm_nn serves, made in ONE launch per eight weights at the start of a backward region instead of one
+# launch per layer inside it (Point-M2AE: 19 small layers).  mm_nn remembers the bf16 shadows it was asked about (views of the flat
+# optimizer's shadow buffer: same address every step; forgotten whenever an optimizer registers new shadows -- forget_transposes);
+# prepare_transposes() transposes them; the cache holds for the region only (the weights change with every optimizer step).
+_tr_known = {}
+_tr_cache = None
+
+
+def _tr_key(w):
+    return (w.data_ptr(), tuple(w.shape))
+
+
+def forget_transposes():
+    _tr_known.clear()
+    drop_transposes()
+
+
+def prepare_transposes():
+    global _tr_cache
+    live = list(_tr_known.values())
+    _tr_cache = {}
+    for i in range(0, len(live), 8):
+        chunk = live[i:i + 8]
+        outs = stacked_transposes([[w] for w in chunk]) if len(chunk) > 1 else [transposed(chunk[0]).unsqueeze(0)]
+        for w, o in zip(chunk, outs):
+            _tr_cache[_tr_key(w)] = o[0]
+
+
+def drop_transposes():
+    global _tr_cache
+    _tr_cache = None
+
+
+def _transposed_for_mm_nn(w):
+    if _tr_cache is not None:
+        hit = _tr_cache.get(_tr_key(w))
+        if hit is not None:
+            return hit
+        if (len(_tr_known) < 64 and w.is_contiguous() and w.dtype == torch.bfloat16 and w.shape[0] % 8 == 0 and w.shape[1] % 8 == 0
+                and w.data_ptr() % 16 == 0 and not torch.cuda.is_current_stream_capturing()):
+            _tr_known.setdefault(_tr_key(w), w)           # asked for inside a region: ready at the start of the next one
+    return transposed(w.contiguous())
+
+
 def mm_nn(x, w, out=None):
     """x (M,N) @ w (N,K) -> (M,K): the input gradient dY . W of a Linear / Conv1d(k=1) layer with weight w (N,K).  bf16 operands
     run as the TN product against a transposed copy of w (one small transposing launch per call: the weights of the layers this
     serves have 32 K .. 512 K elements); anything else goes to torch.mm."""
     if (ENABLED and x.is_cuda and x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
             and w.shape[1] % 8 == 0 and w.shape[0] % 8 == 0 and x.stride(1) == 1 and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0):
-        wt = transposed(w.contiguous())
+        wt = _transposed_for_mm_nn(w)
         if supported(x, wt) or ragged_supported(x, wt):
             return mm(x, wt, None, out)
     y = x @ w
