@@ -30,13 +30,43 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
-PMC_FILE = "r03_pmc_fetch_write_per_launch.json"     # tools/pmc_summary.py over the two --pmc passes of this bench (profiles/README.md)
-PMC_SOURCES = "r03_pmc_sources.json"                 # {"sha16": hash of gm3d_amd/csrc at the time of those passes} -> staleness is visible
+PMC_FILE = "r04_pmc_fetch_write_per_launch.json"     # tools/pmc_summary.py over the two --pmc passes of this bench (profiles/README.md)
+PMC_SOURCES = "r04_pmc_sources.json"                 # {"sha16": hash of gm3d_amd/csrc at the time of those passes} -> staleness is visible
+PMC_FILE_M2AE = "r04_m2ae_pmc_fetch_write_per_launch.json"   # the same two passes over tools/bench_m2ae.py (the Point-M2AE step)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}   # dense
 
-# SURVEY.md 8(d) per-unit algorithmic figures (bytes unless noted) -> per launch
+# SURVEY.md 8(d) per-unit algorithmic figures -> per launch.  GEMM-class kernels have BOTH a flop count and an operand-byte count: the
+# roof that gives the larger time is the one the kernel is graded against (a fabric-bound weight-gradient launch must
+# not be priced against the matrix cores).
+def _gemm_both(flop, nbytes, dtype="bf16"):
+    t_mfma = flop / (MFMA_PEAK_TFLOPS[dtype] * 1e12)
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+    return {"flop": flop, "bytes": nbytes, "bound": "mfma" if t_mfma >= t_hbm else "hbm"}
+
+
+def algorithmic_both(name, meta):
+    """-> {"flop", "bytes", "bound"} for a GEMM-class kernel (bf16 operands, fp32 weight gradients), else None."""
+    if name.startswith("gm3d_gemm_tn_bf16"):   # A (M,K) + W (N,K) in, C (M,N) out, bf16
+        M, N, K = meta["M"], meta["N"], meta["K"]
+        return _gemm_both(2.0 * M * N * K, 2.0 * (M * K + N * K + M * N))
+    if name == "gm3d_gemm_nt_bf16":            # dY (B,R,N) + X (B,R,K) in (bf16), dW (B,N,K) out (f32)
+        B, R, N, K = meta["B"], meta["M"], meta["N"], meta["K"]
+        return _gemm_both(2.0 * B * R * N * K, B * (2.0 * R * (N + K) + 4.0 * N * K))
+    if name == "gm3d_gemm_nt_bf16_multi" and "problems" in meta:
+        flop = sum(2.0 * b * r * n * k for b, r, n, k in meta["problems"])
+        nbytes = sum(b * (2.0 * r * (n + k) + 4.0 * n * k) for b, r, n, k in meta["problems"])
+        return _gemm_both(flop, nbytes)
+    if name == "gm3d_attention_qkv_fwd":       # h (B,T,C) + Wqkv (3C,C) in, out (B,T,C)
+        B, T, H, C = meta["B"], meta["T"], meta["H"], meta["C"]
+        return _gemm_both(B * H * (2.0 * T * 192 * C + 4.0 * T ** 2 * 64), 2.0 * (2 * B * T * C + 3 * C * C))
+    return None
+
+
 def algorithmic(name, meta):
     """-> (bound, amount per launch, unit) for one launch of a hand-written kernel."""
+    both = algorithmic_both(name, meta)
+    if both is not None:
+        return (both["bound"], both["flop"], "FLOP") if both["bound"] == "mfma" else ("hbm", both["bytes"], "B")
     if name == "gm3d_fps":            # 12,288 B xyz + 256 B idx + 768 B centres per cloud
         return "hbm", meta["B"] * (meta["N"] * 12 + meta["npoint"] * 4 + meta["npoint"] * 12), "B"
     if name == "gm3d_knn_group":      # xyz + centres in; idx int64 + neighbourhood + neighbourhood_org out
@@ -46,25 +76,29 @@ def algorithmic(name, meta):
         return "hbm", meta["P"] * ((meta["n"] + meta["m"]) * 12 + (meta["n"] + meta["m"]) * 8), "B"
     if name == "gm3d_chamfer_bwd":    # clouds + idx + grads in, 2 gradient clouds out
         return "hbm", meta["P"] * ((meta["n"] + meta["m"]) * (12 + 4 + 4 + 12)), "B"
+    sz = 2 if "bfloat16" in str(meta.get("dtype", "")) else 4
+    if name == "gm3d_patch_chamfer_loss_fwd":     # per masked patch: 32 predicted + 32 true points in; 2 x 32 neighbour ids + its loss out
+        return "hbm", meta["B"] * meta["M"] * (96 * sz + 384 + 256 + 4), "B"
+    if name == "gm3d_patch_chamfer_loss_bwd":     # per masked patch: both patches + ids in, 96 gradient values out (the visible rows' zeros not counted)
+        return "hbm", meta["B"] * meta["M"] * (96 * sz + 384 + 256 + 96 * sz), "B"
+    if name == "gm3d_adamw_ema_flat_step":        # per parameter: P, G, M, V, E read; P, M, V, E written (f32); two bf16 shadows written
+        return "hbm", meta["n"] * (9 * 4 + 2 * 2 if meta.get("ema", True) else 7 * 4 + 2), "B"
     if name == "gm3d_attention_fwd":  # QK^T + PV: 4*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * 64, "FLOP"
-    if name == "gm3d_attention_qkv_fwd":  # the head's q|k|v projection (T x 192 x C) + QK^T + PV per (b,h)
-        return "mfma", meta["B"] * meta["H"] * (2.0 * meta["T"] * 192 * meta["C"] + 4.0 * meta["T"] ** 2 * 64), "FLOP"
     if name == "gm3d_attention_masked_fwd":   # masked attention of the hierarchical encoder: the dense count (blocked pairs are computed too)
         return "mfma", meta["B"] * meta["H"] * 4.0 * meta["T"] ** 2 * meta["HD"], "FLOP"
     if name == "gm3d_attention_masked_bwd":
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * meta["HD"], "FLOP"
     if name == "gm3d_attention_bwd":  # 5 products (S, dP, dV, dK, dQ): 10*T^2*64 flop per (b,h)
         return "mfma", meta["B"] * meta["H"] * 10.0 * meta["T"] ** 2 * 64, "FLOP"
-    if name.startswith("gm3d_gemm_tn_bf16"):   # own MFMA GEMMs (+ epilogues; register-prefetch and LDS-DMA ring forms): 2*M*N*K flop
-        return "mfma", 2.0 * meta["M"] * meta["N"] * meta["K"], "FLOP"
-    if name == "gm3d_gemm_nt_bf16":            # own weight-gradient GEMM, batched: 2*B*R*N*K flop (meta M = reduction rows)
-        return "mfma", 2.0 * meta["B"] * meta["M"] * meta["N"] * meta["K"], "FLOP"
-    sz = 2 if "bfloat16" in str(meta.get("dtype", "")) else 4
     if name == "gm3d_residual_ln_fwd":   # res in/out fp32, y + add in, h out
         return "hbm", meta["R"] * 384 * (8 + 3 * sz), "B"
     if name == "gm3d_residual_ln_bwd":   # dh, gin, x in; dx, dy out (+ acc read-modify-write on some calls, not counted)
         return "hbm", meta["R"] * 384 * (12 + 2 * sz), "B"
+    if name == "gm3d_add_ln_fwd":        # x, y, z in; s, h out (the any-width residual LayerNorm of the hierarchical model)
+        return "hbm", meta["R"] * meta["C"] * 5 * sz, "B"
+    if name == "gm3d_add_ln_bwd":        # dh, gin, x in; dx, dy out
+        return "hbm", meta["R"] * meta["C"] * 5 * sz, "B"
     if name == "gm3d_bias_gelu_fwd":
         return "hbm", meta["R"] * meta["C"] * 2 * sz, "B"
     if name == "gm3d_bias_gelu_bwd":
@@ -86,20 +120,58 @@ def algorithmic(name, meta):
     return None
 
 
+def roofline_of(name, per_launch, total_ms, dtype="bf16"):
+    """One kernel over all its timed launches [(ms, meta), ...] -> {"bound", "achieved", "peak", "unit", "frac", "amount"} (amount =
+    algorithmic work per launch in the bound's unit), or None when the kernel has no algorithmic figure.  GEMM-class kernels: flops and
+    operand bytes are summed over the launches, the roof that gives the larger time is THE bound, and both rates are reported
+    ("mfma": TFLOP/s + frac_mfma, "hbm": GB/s + frac_hbm)."""
+    metas = [m for _, m in per_launch]
+    if not metas or algorithmic(name, metas[0]) is None:
+        return None
+    secs = total_ms * 1e-3
+    both = [algorithmic_both(name, m) for m in metas]
+    if all(b is not None for b in both):
+        flop, nbytes = sum(b["flop"] for b in both), sum(b["bytes"] for b in both)
+        t_mfma, t_hbm = flop / (MFMA_PEAK_TFLOPS[dtype] * 1e12), nbytes / (HBM_PEAK_GBS * 1e9)
+        bound = "mfma" if t_mfma >= t_hbm else "hbm"
+        out = {"bound": bound, "tflops": round(flop / secs / 1e12, 2), "frac_mfma": round(t_mfma / secs, 4),
+               "gbs": round(nbytes / secs / 1e9, 1), "frac_hbm": round(t_hbm / secs, 4)}
+        if bound == "mfma":
+            out.update(achieved=flop / secs / 1e12, peak=MFMA_PEAK_TFLOPS[dtype], unit="TFLOP/s", amount=flop / len(metas), amount_unit="FLOP")
+        else:
+            out.update(achieved=nbytes / secs / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", amount=nbytes / len(metas), amount_unit="B")
+        out["frac"] = out["achieved"] / out["peak"]
+        return out
+    bound, _, unit = algorithmic(name, metas[0])
+    work = sum(algorithmic(name, m)[1] for m in metas)
+    if bound == "hbm":
+        out = {"bound": "hbm", "achieved": work / secs / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s"}
+    else:
+        out = {"bound": "mfma", "achieved": work / secs / 1e12, "peak": MFMA_PEAK_TFLOPS[dtype], "unit": "TFLOP/s"}
+    out.update(frac=out["achieved"] / out["peak"], amount=work / len(metas), amount_unit=unit)
+    return out
+
+
 def _gemm_grid(meta):
     tiles = -(-meta["M"] // 128) * (meta["N"] // 128)
     return (tiles + 7) // 8 * 8 * 256
 
 
-def pmc_traffic(kernel, dtype, metas=()):
+def pmc_traffic(kernel, dtype, metas=(), pmc_file=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and --pmc
     WRITE_SIZE runs of this same bench, eager, summarised in profiles/r02_pmc_fetch_write_per_launch.json), corrected as
     MI355X_MICROARCH.md prescribes for gfx950: counters are in KB, and FETCH_SIZE reports half of a coalesced stream.
     Launch-weighted mean over the kernel's shapes in the step.  None when no measurement is on file."""
-    path = os.path.join(ROOT, "profiles", PMC_FILE)
+    path = os.path.join(ROOT, "profiles", pmc_file or PMC_FILE)
     if not os.path.exists(path):
         return None
-    if kernel == "gm3d_gemm_tn_bf16_ring":
+    special = {"gm3d_gemm_nt_bf16_multi": "gm3d::gemm_nt_multi_kernel", "gm3d_adamw_ema_flat_step": "gm3d::adamw_ema_flat_kernel",
+               "gm3d_gemm_tn_bf16_ws": "gm3d::gemm_tn_ws_kernel", "gm3d_gemm_tn_bf16_ws_pool": "gm3d::gemm_tn_ws_kernel",
+               "gm3d_attention_masked_fwd": "gm3d::mattn_fwd_bf16_kernel", "gm3d_attention_masked_bwd": "gm3d::mattn_bwd_bf16_kernel",
+               "gm3d_add_ln_fwd": "gm3d::ln_plain_fwd_kernel", "gm3d_add_ln_bwd": "gm3d::ln_plain_bwd_kernel"}
+    if kernel in special:
+        rows = [r for r in json.load(open(path)) if r["kernel"].startswith(special[kernel])]
+    elif kernel == "gm3d_gemm_tn_bf16_ring":
         rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_ring_kernel")]
     elif kernel.startswith("gm3d_gemm_tn_bf16_dma"):
         rows = [r for r in json.load(open(path)) if r["kernel"].startswith("gm3d::gemm_tn_dma_kernel")]
@@ -261,6 +333,32 @@ def secondary(device, replays=10):
             return res
         r = timed(step, B)
         r["workload"] = "Point-M2AE+GM3D pretrain step: B=128 clouds of 2048 points, G=512/256/64, k=16/8/8, dims 96/192/384"
+        # roofline of this step's dominant hand-written kernel (HIP-event brackets over two eager steps right after the replays; the
+        # counters behind `traffic` are the committed --pmc passes over tools/bench_m2ae.py)
+        from gm3d_amd import ops as O
+        probe = O.KernelTimer()
+        O.set_kernel_timer(probe)
+        try:
+            for i in range(2):
+                P.pretrain_step(model, ema, opt, pool[i].clone(), 100, ma)
+        finally:
+            O.set_kernel_timer(None)
+        ps = probe.summary()
+        cand = [n for n in ps if algorithmic(n, ps[n]["meta"])]
+        if cand:
+            dom = max(cand, key=lambda n: ps[n]["total_ms"])
+            rf = roofline_of(dom, ps[dom]["per_launch"], ps[dom]["total_ms"])
+            r["roofline"] = {"kernel": dom, "bound": rf["bound"], "achieved": rf["achieved"], "peak": rf["peak"], "unit": rf["unit"],
+                             "frac": rf["frac"], "traffic": pmc_traffic(dom, "bf16", [m for _, m in ps[dom]["per_launch"]], PMC_FILE_M2AE),
+                             "avg_launch_us": ps[dom]["avg_ms"] * 1e3, "launches_per_step": ps[dom]["launches"] / 2,
+                             "ms_per_step": ps[dom]["total_ms"] / 2, "algorithmic_per_launch": rf["amount"], "algorithmic_unit": rf["amount_unit"],
+                             "both_bounds": {k: rf[k] for k in ("tflops", "frac_mfma", "gbs", "frac_hbm") if k in rf} or None}
+            top = sorted(cand, key=lambda n: -ps[n]["total_ms"])[:8]
+            r["kernel_rooflines"] = {}
+            for n in top:
+                q = roofline_of(n, ps[n]["per_launch"], ps[n]["total_ms"])
+                r["kernel_rooflines"][n] = {"bound": q["bound"], "frac": round(q["frac"], 4), "achieved": round(q["achieved"], 2), "unit": q["unit"],
+                                            "ms_per_step": round(ps[n]["total_ms"] / 2, 3), "launches_per_step": ps[n]["launches"] / 2}
         return r
 
     for name, fn in (("finetune_modelnet", finetune), ("published_run", published), ("point_m2ae", m2ae)):
@@ -532,25 +630,18 @@ def main():
         # kernel is in profiles/), so `achieved` here is the conservative figure; the empty-bracket time is reported.
         overhead_ms = ops.KernelTimer.bracket_overhead_ms()
         raw_avg_ms = tsum["avg_ms"]
-        bound, _, unit = algorithmic(dominant, tsum["meta"])
         # the kernel runs on several shapes per step (e.g. 8192- and 3200-row token streams): algorithmic work and time
         # are summed over the timed launches, so `achieved` is total work / total kernel time
-        amount = sum(algorithmic(dominant, m)[1] for _, m in tsum["per_launch"]) / tsum["launches"]
-        if bound == "hbm":
-            achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            achieved, peak, runit = amount / (tsum["avg_ms"] * 1e-3) / 1e12, MFMA_PEAK_TFLOPS[dtype], "TFLOP/s"
-        # every hand-written kernel against its own roofline (eager probe steps, raw event brackets)
+        dom = roofline_of(dominant, tsum["per_launch"], tsum["total_ms"], dtype)
+        bound, achieved, peak, runit, amount, unit = dom["bound"], dom["achieved"], dom["peak"], dom["unit"], dom["amount"], dom["amount_unit"]
+        # every hand-written kernel against its own roofline (eager probe steps, raw event brackets); GEMM-class kernels carry both
+        # rates (tflops / frac_mfma, gbs / frac_hbm) and `bound` names the roof that binds
         all_roof = {}
         for n, v in psum.items():
-            if not algorithmic(n, v["meta"]):
+            r_ = roofline_of(n, v["per_launch"], v["total_ms"], dtype)
+            if r_ is None:
                 continue
-            b_, _, _ = algorithmic(n, v["meta"])
-            work = sum(algorithmic(n, m)[1] for _, m in v["per_launch"])
-            rate = work / (v["total_ms"] * 1e-3)
-            pk = HBM_PEAK_GBS * 1e9 if b_ == "hbm" else MFMA_PEAK_TFLOPS[dtype] * 1e12
-            all_roof[n] = {"bound": b_, "achieved": round(rate / (1e9 if b_ == "hbm" else 1e12), 2),
-                           "unit": "GB/s" if b_ == "hbm" else "TFLOP/s", "frac": round(rate / pk, 4)}
+            all_roof[n] = {k: (round(x, 4) if isinstance(x, float) else x) for k, x in r_.items() if k not in ("amount", "amount_unit", "peak")}
         for v in psum.values():
             v.pop("per_launch", None)
         per_step = {n: {"launches_per_step": v["launches"] / nprobe,
@@ -580,6 +671,7 @@ def main():
                          "frac": achieved / peak, "traffic": pmc_traffic(dominant, dtype, [m for _, m in tsum["per_launch"]]),
                          "avg_launch_us": raw_avg_ms * 1e3, "empty_bracket_us": overhead_ms * 1e3, "launches_timed": tsum["launches"],
                          "algorithmic_per_launch": amount, "algorithmic_unit": unit, "timing": roofline_timing,
+                         "both_bounds": {k: dom[k] for k in ("tflops", "frac_mfma", "gbs", "frac_hbm") if k in dom} or None,
                          "traffic_source": pmc_source()},
             "execution": ("hipGraph replay" + ((" (4 graphs: segment all-reduces overlap the next backward segment)" if segmented else
                                              " (fwd+bwd | all-reduce | update)") if use_dist else "")) if use_graph

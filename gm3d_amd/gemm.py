@@ -536,7 +536,8 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
         outs.append(out)
         spl.append(s_)
         parts.append(torch.empty(nb, s_, N, K, dtype=torch.float32, device=dy.device) if s_ > 1 else None)
-    _launch("gm3d_gemm_nt_bf16_multi", {"count": n}, lib.gm3d_gemm_nt_bf16_multi, n,
+    _launch("gm3d_gemm_nt_bf16_multi", {"count": n, "problems": [(r[0].shape[0], r[0].shape[1], r[0].shape[2], r[1].shape[2]) for r in reqs],
+                                        "splits": list(spl)}, lib.gm3d_gemm_nt_bf16_multi, n,
             VP(*[_ptr(r[0]) for r in reqs]), VP(*[_ptr(r[1]) for r in reqs]), VP(*[_ptr(o) for o in outs]),
             VP(*[(_ptr(p) if p is not None else None) for p in parts]), I(*[r[0].shape[0] for r in reqs]), I(*[r[0].shape[1] for r in reqs]),
             I(*[r[0].shape[2] for r in reqs]), I(*[r[1].shape[2] for r in reqs]), I(*[r[0].stride(1) for r in reqs]),

@@ -301,9 +301,10 @@ class FlatAdamWEma(torch.optim.Optimizer):
             elif getattr(self, "_ema_w_host", None) != w:
                 self.ema_w_dev.fill_(w)
                 self._ema_w_host = w
-        check(lib.gm3d_adamw_ema_flat_step_lrd(
-            _ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS), _ptr(self.ES), self.n,
-            self.n_decay, _ptr(self.lr_dev), _ptr(self.LS), float(g["weight_decay"]), float(g["betas"][0]),
-            float(g["betas"][1]), float(g["eps"]), _ptr(self.ema_w_dev), self.max_norm, _ptr(self.step_dev),
-            _ptr(self.partial), _ptr(self.scal), _stream()), "gm3d_adamw_ema_flat_step_lrd")
+        from .ops import _launch
+        _launch("gm3d_adamw_ema_flat_step", {"n": self.n, "ema": self.E is not None}, lib.gm3d_adamw_ema_flat_step_lrd,
+                _ptr(self.P), _ptr(self.G), _ptr(self.M), _ptr(self.V), _ptr(self.E), _ptr(self.PS), _ptr(self.ES), self.n,
+                self.n_decay, _ptr(self.lr_dev), _ptr(self.LS), float(g["weight_decay"]), float(g["betas"][0]),
+                float(g["betas"][1]), float(g["eps"]), _ptr(self.ema_w_dev), self.max_norm, _ptr(self.step_dev),
+                _ptr(self.partial), _ptr(self.scal), _stream())
         return self.scal[3]

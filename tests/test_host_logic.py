@@ -213,3 +213,31 @@ def test_run_epoch_without_a_model_key():
     stats = E.run_epoch(loader, opt, torch.device("cpu"), 0, args, eager_step, capture=lambda ex: None, print_freq=100)
     assert seen == [0, 1, 2, 3]
     assert abs(stats["loss"] - 1.5) < 1e-6 and abs(stats["grad_norm"] - 3.0) < 1e-6 and stats["replayed_iters"] == 0
+
+
+def test_roofline_bookkeeping_has_both_bounds_and_the_named_kernels():
+    """gm3d_gemm_nt_bf16_multi, gm3d_patch_chamfer_loss_fwd/bwd and gm3d_adamw_ema_flat_step have algorithmic
+    figures, and a GEMM-class kernel is graded against the roof that gives the larger time (flops vs operand bytes)."""
+    import bench
+    # the stacks' weight-gradient launch of the north-star step: 12 products over 8192 / 3328 rows
+    probs = [(12, 8192, 1536, 384), (12, 8192, 384, 1536), (12, 8192, 384, 384), (12, 8192, 1152, 384)]
+    meta = {"count": 4, "problems": probs}
+    both = bench.algorithmic_both("gm3d_gemm_nt_bf16_multi", meta)
+    flop = sum(2.0 * b * r * n * k for b, r, n, k in probs)
+    assert both["flop"] == flop and both["bytes"] == sum(b * (2.0 * r * (n + k) + 4.0 * n * k) for b, r, n, k in probs)
+    assert both["bound"] == ("mfma" if flop / 2.5e15 >= both["bytes"] / 8e12 else "hbm")
+    # a skinny product (65,536 x 96 -> 288) is an HBM stream, a square one is matrix-core work
+    assert bench.algorithmic("gm3d_gemm_tn_bf16_ws", {"M": 65536, "N": 288, "K": 96})[0] == "hbm"
+    assert bench.algorithmic("gm3d_gemm_tn_bf16_dmaw", {"M": 8192, "N": 1536, "K": 1536})[0] == "mfma"
+    # (fc1 of the north-star blocks, 8192 x 384 -> 1536, sits just below the ridge of 312 FLOP/B: 296 -- the operand bytes bind)
+    assert bench.algorithmic("gm3d_gemm_tn_bf16_dmaw", {"M": 8192, "N": 1536, "K": 384})[0] == "hbm"
+    for name, m in (("gm3d_patch_chamfer_loss_fwd", {"B": 128, "M": 39, "dtype": "torch.float32"}),
+                    ("gm3d_patch_chamfer_loss_bwd", {"B": 128, "M": 39, "dtype": "torch.float32"}),
+                    ("gm3d_adamw_ema_flat_step", {"n": 36_000_000, "ema": True})):
+        b, amount, unit = bench.algorithmic(name, m)
+        assert b == "hbm" and unit == "B" and amount > 0
+    # mixed launches of one kernel: work summed per roof, one bound for the whole
+    per = [(0.010, {"M": 65536, "N": 288, "K": 96}), (0.020, {"M": 8192, "N": 384, "K": 1536})]
+    r = bench.roofline_of("gm3d_gemm_tn_bf16_ring", per, 0.030)
+    assert r["bound"] in ("mfma", "hbm") and 0 < r["frac"] < 1 and {"tflops", "gbs", "frac_mfma", "frac_hbm"} <= set(r)
+    assert abs(r["frac"] - max(r["frac_mfma"], r["frac_hbm"])) < 1e-3

@@ -5,7 +5,7 @@ from types import SimpleNamespace
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from gm3d_amd import engine_pretrain as E, point_m2ae as P
-from bench import make_clouds, algorithmic
+from bench import make_clouds, roofline_of
 from gm3d_amd import ops
 
 ap = argparse.ArgumentParser()
@@ -17,7 +17,7 @@ a = ap.parse_args()
 if a.narrow_attn:
     from gm3d_amd._capi import lib as _lib
     _lib.gm3d_attention_masked_set_wide(0)
-E.enable_tuned_gemms()        # this model still hands its 96- / 288- / 576-wide products to the library (K % 64 != 0 or N % 128 != 0)
+# (no TunableOp table: since round 4 every product of this step runs on a hand-written kernel -- rocprof: 0 library launches)
 torch.manual_seed(0)
 model = P.PointM2AE().cuda().train()
 ema = E.ModelEma(model, 0.999)
@@ -69,14 +69,13 @@ for i in range(2):
 ops.set_kernel_timer(None)
 roof = {}
 for n, v in probe.summary().items():
-    try:
-        b_, _, unit = algorithmic(n, v["meta"])
-        work = sum(algorithmic(n, m)[1] for _, m in v["per_launch"])
-    except Exception:
+    q = roofline_of(n, v["per_launch"], v["total_ms"])
+    if q is None:
         continue
-    rate = work / (v["total_ms"] * 1e-3)
-    roof[n] = {"bound": b_, "achieved": round(rate / (1e9 if b_ == "hbm" else 1e12), 2), "unit": "GB/s" if b_ == "hbm" else "TFLOP/s",
-               "frac": round(rate / (8e12 if b_ == "hbm" else 2.5e15), 4), "launches_per_step": v["launches"] / 2,
-               "ms_per_step": round(v["total_ms"] / 2, 3)}
+    roof[n] = {"bound": q["bound"], "achieved": round(q["achieved"], 2), "unit": q["unit"], "frac": round(q["frac"], 4),
+               "launches_per_step": v["launches"] / 2, "ms_per_step": round(v["total_ms"] / 2, 3)}
+    for k in ("tflops", "frac_mfma", "gbs", "frac_hbm"):
+        if k in q:
+            roof[n][k] = q[k]
 line["kernel_rooflines"] = dict(sorted(roof.items(), key=lambda kv: -kv[1]["ms_per_step"])[:10])
 print(json.dumps(line))
