@@ -79,6 +79,19 @@ template <int HD> struct MImg {
     }
 };
 
+// Workgroup -> (cloud * head, tile block) with the workgroups of ONE cloud on ONE XCD.  The hardware deals consecutive workgroup ids to
+// the 8 XCDs round-robin, and the qkv layout (B,T,3,H,hd) interleaves the heads of a cloud within every 2 H hd-byte row (32-byte
+// pieces at hd = 16): with id = cloud * H + head the six heads of a cloud pull the same lines into six different L2s (PMC, T = 512,
+// hd = 16: 527 MB fetched for 63 MB of operands in the backward).  Remapped, id' = (id % 8) * (total / 8) + id / 8 runs through the
+// (tile block, head, cloud) triples in order on each XCD.
+__device__ __forceinline__ void mattn_block(int& bh, int& yb) {
+    const int nx = gridDim.x, ny = gridDim.y, total = nx * ny;
+    int lin = blockIdx.x + nx * blockIdx.y;
+    if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+    yb = lin % ny;
+    bh = lin / ny;
+}
+
 // word `kt` of mask row `i` with the keys >= T of that word forced on; rows >= T: everything masked
 __device__ __forceinline__ unsigned mask_word(const unsigned* mrow /* row i, or nullptr */, bool row_ok, int kt, int T) {
     unsigned w = mrow ? mrow[kt] : 0u;
@@ -103,12 +116,14 @@ __global__ __launch_bounds__(64 * NWV) void mattn_fwd_bf16_kernel(const bf16_t* 
     unsigned char* Ki = msm;
     unsigned char* Vi = Ki + rowsK * I::PITCH;
     unsigned char* Qi = Vi + rowsK * I::PITCH;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    int bh_, yb_;
+    mattn_block(bh_, yb_);
+    const int b = bh_ / H, h = bh_ % H;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
     const bf16_t* Qg = qkv + (size_t)b * T * rs + (size_t)h * HD;
-    const int q0 = 32 * NWV * blockIdx.y;
+    const int q0 = 32 * NWV * yb_;
     I::stage(Ki, Qg + os, rs, T, rowsK, tid, 64 * NWV);
     I::stage(Vi, Qg + 2 * os, rs, T, rowsK, tid, 64 * NWV);
     I::stage(Qi, Qg + (size_t)q0 * rs, rs, T - q0, 32 * NWV, tid, 64 * NWV);
@@ -201,7 +216,9 @@ __global__ __launch_bounds__(128 * NTP) void mattn_bwd_bf16_kernel(const bf16_t*
     unsigned char* Di = Vi + rows * I::PITCH;
     float* Ls = reinterpret_cast<float*>(Di + rows * I::PITCH);
     float* Del = Ls + rows;
-    const int b = blockIdx.x / H, h = blockIdx.x % H;
+    int bh_, yb_;
+    mattn_block(bh_, yb_);
+    const int b = bh_ / H, h = bh_ % H;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(128 * NTP) void mattn_bwd_bf16_kernel(const bf16_t*
     __syncthreads();
     bf16_t* dQg = dqkv + (size_t)b * T * rs + (size_t)h * HD;
     const int cb = 16 * ((lane >> 4) & 1);
-    const int tile = NTP * blockIdx.y + (w < NTP ? w : w - NTP);
+    const int tile = NTP * yb_ + (w < NTP ? w : w - NTP);
     if (32 * tile >= T) return;                     // wave-uniform; no barrier follows
     const int row = 32 * tile + r;                  // this lane's key (waves 0..3) or query (waves 4..7)
     const bool row_ok = row < T;
