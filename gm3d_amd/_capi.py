@@ -85,6 +85,7 @@ SIGNATURES = {
     "gm3d_gemm_ws_supported": [_i, _i, _i],
     "gm3d_gemm_tn_bf16_ws_poolg": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_nt_set_big_tiles": [_i],
+    "gm3d_gemm_nt_set_order": [_i],
     "gm3d_gemm_nt_bf16_sum": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _i, _vp],
     "gm3d_gemm_nt_tiles": [_i, _i],
     "gm3d_gemm_nt_bf16_multi": [_i] + [_vp] * 14 + [_vp],

@@ -62,12 +62,13 @@ __device__ __forceinline__ nbf16x8 nt_frag(const unsigned char* img, int kk0, in
 __device__ __forceinline__ void nt_tile(unsigned char* nsm, const bf16_t* __restrict__ Y, const bf16_t* __restrict__ X, float* __restrict__ O,
                                         int rows_split, int ldy, int ldx, int ldo, long long sY, long long sX, long long sO, long long sOs,
                                         int splits, int tiles_n, int tiles_k, int logical, int Nfull, int Kfull, int* __restrict__ counters,
-                                        float* __restrict__ Ofin, long long sOfin, int ldofin) {
+                                        float* __restrict__ Ofin, long long sOfin, int ldofin, int tn_fastest = 0) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     int t = logical;
-    const int tk = t % tiles_k; t /= tiles_k;
-    const int tn = t % tiles_n; t /= tiles_n;
+    int tk, tn;
+    if (tn_fastest) { tn = t % tiles_n; t /= tiles_n; tk = t % tiles_k; t /= tiles_k; }     // measurement knob (gm3d_gemm_nt_set_order)
+    else { tk = t % tiles_k; t /= tiles_k; tn = t % tiles_n; t /= tiles_n; }
     const int sp = t % splits;
     const int b = t / splits;
     const int n0 = tn * 128, k0 = tk * 128;
@@ -212,6 +213,7 @@ struct NtProblem {
 constexpr int NT_MAXP = 16;
 struct NtMulti {
     int count;
+    int tn_fastest;
     NtProblem p[NT_MAXP];
 };
 
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_multi_kernel(NtMulti m) {
     const int logical = (local & 7) * per_xcd + (local >> 3);
     if (logical >= q.total) return;
     nt_tile(nsm, q.Y, q.X, q.O, q.rows_split, q.ldy, q.ldx, q.ldo, q.sY, q.sX, q.sO, q.sOs, q.splits, q.tiles_n, q.tiles_k, logical, q.N, q.K,
-            nullptr, nullptr, 0, 0);
+            nullptr, nullptr, 0, 0, m.tn_fastest);
 }
 
 // ---- 128 x 384 output tiles (the block stacks' weight gradients: every (N, K) there is a multiple of (128, 384)) ----------------------
@@ -499,6 +501,12 @@ __global__ __launch_bounds__(256) void nt_sum_multi_kernel(NtSumMulti m) {
 // that adds the row-split slabs of every problem with splits > 1 (part[j]: (batch, splits, N, K) f32 scratch; out[j]: (batch, N, K)
 // contiguous rows of K, batch stride stride_o[j]).  Problems with splits == 1 write out[j] directly.  Results are bit-identical to the
 // separate launches (same tiles, same slab order).
+static int NT_MULTI_TN_FASTEST = 0;
+extern "C" int gm3d_gemm_nt_set_order(int tn_fastest) {
+    NT_MULTI_TN_FASTEST = tn_fastest ? 1 : 0;
+    return GM3D_OK;
+}
+
 extern "C" int gm3d_gemm_nt_bf16_multi(int count, const void* const* dY, const void* const* X, float* const* out, float* const* part,
                                        const int* batch, const int* R, const int* N, const int* K, const int* ldy, const int* ldx,
                                        const long long* stride_y, const long long* stride_x, const long long* stride_o, const int* splits,
@@ -510,6 +518,7 @@ extern "C" int gm3d_gemm_nt_bf16_multi(int count, const void* const* dY, const v
     NtMulti m;
     NtSumMulti sm;
     m.count = count;
+    m.tn_fastest = NT_MULTI_TN_FASTEST;
     sm.count = 0;
     long long first = 0;
     int max_batch = 1;

@@ -491,6 +491,11 @@ MULTI_WGRAD = True        # the weight gradients of several stacks as ONE launch
 #                           slabs to write and add): 7.56 vs 7.65 ms, +1.1 %
 
 
+NT_TN_FASTEST = False     # measurement knob: tile order inside a (block, row-split) group of the one-launch weight gradients (csrc/gemm_nt.hip
+#                           gm3d_gemm_nt_set_order): PMC and step time equal either way (profiles/NEGATIVE_RESULTS.md, round 4)
+_nt_order_set = [False]
+
+
 def wgrad_multi_ok(dy, x, out):
     """a request wgrad_nt_multi takes: what wgrad_nt takes, with a destination of dense (N,K) matrices at a constant batch stride"""
     nb, R, N = dy.shape
@@ -536,6 +541,9 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
         outs.append(out)
         spl.append(s_)
         parts.append(torch.empty(nb, s_, N, K, dtype=torch.float32, device=dy.device) if s_ > 1 else None)
+    if _nt_order_set[0] != bool(NT_TN_FASTEST):
+        lib.gm3d_gemm_nt_set_order(int(bool(NT_TN_FASTEST)))
+        _nt_order_set[0] = bool(NT_TN_FASTEST)
     _launch("gm3d_gemm_nt_bf16_multi", {"count": n, "problems": [(r[0].shape[0], r[0].shape[1], r[0].shape[2], r[1].shape[2]) for r in reqs],
                                         "splits": list(spl)}, lib.gm3d_gemm_nt_bf16_multi, n,
             VP(*[_ptr(r[0]) for r in reqs]), VP(*[_ptr(r[1]) for r in reqs]), VP(*[_ptr(o) for o in outs]),

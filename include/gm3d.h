@@ -525,6 +525,9 @@ int gm3d_gemm_nt_splits(int batch, int R, int N, int K);
  * software-pipelined against the MFMAs; measured SLOWER on MI355X, kept as a tested variant).  Results are equal for equal row splits;
  * gm3d_gemm_nt_splits follows the setting.  Process-wide measurement knob; set before capturing a graph. */
 int gm3d_gemm_nt_set_big_tiles(int on);
+/* measurement knob of gm3d_gemm_nt_bf16_multi: tile order inside a (block, row-split) group -- 0 (default): the K-tiles of one dY column
+ * block adjacent; 1: the N-tiles of one X column block adjacent */
+int gm3d_gemm_nt_set_order(int tn_fastest);
 /* gm3d_gemm_nt_bf16 with the sum over the row splits INSIDE the launch (no gm3d_sum_few_rows pass): the workgroup that finishes a
  * tile's last slab adds that tile's slabs in slab order (bit-identical to the two-launch form, whatever the arrival order) and writes
  * out (batch, N, ldo; batch stride stride_o; ldo % 4 == 0).  part: (batch, splits, N, K) f32 scratch; counters: batch *
