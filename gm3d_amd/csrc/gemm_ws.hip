@@ -113,9 +113,6 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                 const int p = lw * PPL + q, t = p / (4 * KT), pp = p - t * (4 * KT), kt = pp >> 2, row = 8 * (pp & 3) + prow;
                 const int gr = m0 + 32 * t + row;
                 const int am = gr < M ? gr : M - 1;                  // rows past M: clamped (their outputs are never stored)
-#ifdef GM3D_WS_PROBE_NO_LOAD
-                if (i < DEPTH)
-#endif
                 int col = 64 * kt + ((pslot ^ ws_f(row)) << 3);
                 col = col < Kreal ? col : 0;
                 ws_glds16(A + (size_t)am * lda + col, base + 1024 * p);
@@ -209,18 +206,12 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             // EPI 0: the transposed tile (lane = row, registers = 4 x 4 consecutive columns: whole-row staging).  EPI 3: operands
             // swapped -> lane = COLUMN (lane & 31), registers = 16 of the 32 rows (8 (g >> 2) + 4 hh + (g & 3)), the other 16 in lane ^ 32:
             // the max over rows is 15 register maxima + one cross-lane step.  Same products, same k order: same bits.
-#ifndef GM3D_WS_PROBE_NO_MFMA
 #pragma unroll
             for (int s = 0; s < 4; ++s)
 #pragma unroll
                 for (int t = 0; t < TM; ++t)
                     acc[t] = EPI == 3 ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t][s], wreg[kt][s], acc[t], 0, 0, 0)
                                       : __builtin_amdgcn_mfma_f32_32x32x16_bf16(wreg[kt][s], fa[t][s], acc[t], 0, 0, 0);
-#else
-#pragma unroll
-            for (int t = 0; t < TM; ++t)
-                acc[t][0] += (float)fa[t][0][0] + (float)fa[t][1][1] + (float)fa[t][2][2] + (float)fa[t][3][3] + (float)wreg[kt][0][0];
-#endif
         }
         if (EPI == 3 && !C) __builtin_amdgcn_s_barrier();      // B2 (no rows to stage): tile i's slot may be refilled from here on
         if (EPI == 3) {
@@ -325,9 +316,6 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
                     const int row = c / CH, chunk = c - row * CH;
                     if (m0 + row < M) {
                         const uint4 raw = *reinterpret_cast<const uint4*>(stage + ((row >> 5) * NIMG + (chunk >> 3)) * 4096 + ws_off(row & 31, chunk & 7));
-#ifdef GM3D_WS_PROBE_NO_STORE
-                        if (raw.x == 0x12345678u && raw.y == 0x9abcdef0u)
-#endif
                         *reinterpret_cast<uint4*>(C + (size_t)(m0 + row) * ldc + n0 + 8 * chunk) = raw;
                     }
                 }
