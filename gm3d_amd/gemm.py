@@ -509,7 +509,11 @@ def wgrad_nt_multi(reqs, splits=None, want_splits=False):
     """[(dy (nb,R,N), x (nb,R,K), out (nb,N,K) f32 | None), ...] (at most 16) -> [out, ...]: every product dy[b]^T @ x[b] of every request
     in ONE launch of the 128 x 128-tile weight-gradient kernel, then ONE launch that adds the row-split slabs (csrc/gemm_nt.hip
     gm3d_gemm_nt_bf16_multi).  Bit-identical to wgrad_nt per request with the same row splits (splits=: one per request; default: each
-    request's own choice, capped by MULTI_SPLITS_MAX when the launch is large)."""
+    request's own choice, capped by MULTI_SPLITS_MAX when the launch is large).
+    NOTE: the DEFAULT splits of a request depend on the composition of the whole launch (its total tile count), and the
+    fp32 summation order of a weight gradient follows its splits.  The same product batched differently -- a stack alone, with the
+    deferred decoders, inside SegmentedDDPStep's cut, per-request fallback beyond 16 -- may therefore differ in the last bits
+    (tests/test_gpu_gemm.py::test_wgrad_multi_default_splits_depend_on_the_batch_only_in_the_last_bits pins the size of that: 1e-6)."""
     import ctypes
     n = len(reqs)
     VP, I, LL = ctypes.c_void_p * n, ctypes.c_int * n, ctypes.c_longlong * n

@@ -379,9 +379,9 @@ class ResidualTailFn(torch.autograd.Function):
             dy = torch.empty_like(gin) if rowscale is not None else None
             nrows = lib.gm3d_ln_plain_partial_rows(R)
             part = torch.empty(nrows, 3 * C, dtype=torch.float32, device=gin.device)
-            dummy = torch.ones(max(R, C), dtype=torch.float32, device=gin.device)     # mean / rstd / gamma of a LayerNorm that is not there
-            _launch("gm3d_add_ln_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_bwd, None, _ptr(gin), _ptr(gin), _ptr(dummy),
-                    _ptr(dummy), _ptr(dummy), _ptr(rowscale), int(ctx.rps), _ptr(dx), _ptr(dy), _ptr(part), 3, R, C, _DT[adt], _stream())
+            # dh == NULL: the sum-only backward reads nothing of a LayerNorm that is not there (dx = gin, an Inf stays an Inf)
+            _launch("gm3d_add_ln_bwd", {"R": R, "C": C, "dtype": str(adt)}, lib.gm3d_add_ln_bwd_acc, None, _ptr(gin), None, None,
+                    None, None, _ptr(rowscale), int(ctx.rps), _ptr(dx), _ptr(dy), _ptr(part), 3, None, 0, R, C, _DT[adt], _stream())
             gb = _finish(part, nrows, 3 * C)
             xdt, ydt = ctx.dts
             return dx.view(ctx.shp).to(xdt), (dy if dy is not None else dx).view(ctx.shp).to(ydt), gb[2 * C:].clone(), None, None

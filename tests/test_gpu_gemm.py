@@ -578,3 +578,21 @@ def test_stacked_transposes_one_launch_equals_one_per_group():
         assert torch.equal(o, torch.stack(ws).transpose(1, 2).contiguous())
     one = gemm.stacked_transposes([groups[0]])            # a single group: the per-group path
     assert torch.equal(one[0], got[0])
+
+
+def test_wgrad_multi_default_splits_depend_on_the_batch_only_in_the_last_bits():
+    """wgrad_nt_multi picks a request's row splits from the whole launch's tile count, so the fp32 summation order of one
+    weight gradient depends on what it is batched with.  With explicit splits the result is wgrad_nt's to the bit; with the defaults the
+    same product alone / in a large launch agrees to fp32 rounding of the sum (1e-6 of the largest entry), nothing more."""
+    from gm3d_amd import gemm
+    g = torch.Generator(device="cuda").manual_seed(5)
+    mk = lambda nb, R, N, K: ((torch.randn(nb, R, N, device="cuda", generator=g) * 0.1).bfloat16(), torch.randn(nb, R, K, device="cuda", generator=g).bfloat16())
+    small = mk(4, 8192, 384, 384)
+    others = [mk(12, 8192, 1536, 384), mk(12, 8192, 384, 1536), mk(12, 8192, 1152, 384)]
+    alone, spl_a = gemm.wgrad_nt_multi([(small[0], small[1], None), (others[0][0][:1], others[0][1][:1], None)], want_splits=True)
+    batched, spl_b = gemm.wgrad_nt_multi([(small[0], small[1], None)] + [(a, b, None) for a, b in others], want_splits=True)
+    ref = gemm.wgrad_nt(small[0], small[1], splits=spl_b[0])
+    assert torch.equal(batched[0], ref)                                   # explicit splits == the per-request kernel, bit for bit
+    assert torch.equal(alone[0], gemm.wgrad_nt(small[0], small[1], splits=spl_a[0]))
+    scale = float(ref.abs().max())
+    assert float((alone[0] - batched[0]).abs().max()) <= 2e-6 * scale
