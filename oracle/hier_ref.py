@@ -63,6 +63,13 @@ def _ln(sd, name, x):
     return F.layer_norm(x, (x.shape[-1],), sd[name + ".weight"], sd[name + ".bias"], 1e-5)
 
 
+# How far an INJECTED decision is from the one this restatement would have taken itself: every entry is
+# (kind, margin relative to the tensor's scale).  A sign taken over against a pre-activation that is not within rounding of zero, or a
+# pool winner that is not within rounding of the maximum, would mean the product decided WRONGLY and the comparison merely repeated
+# its mistake; tests assert the margins stay at rounding level (tests/test_gpu_m2ae.py).  Reset by the caller.
+DECISION_MARGINS = []
+
+
 class _Signs:
     """The sign patterns of the activations of another run, consumed in call order (None: decide here)."""
 
@@ -74,6 +81,10 @@ class _Signs:
             return torch.relu(x) if slope == 0.0 else F.leaky_relu(x, slope)
         s = self.signs[self.at].reshape(x.shape)
         self.at += 1
+        with torch.no_grad():
+            wrong = s != (x > 0)
+            m = float(x.detach().abs()[wrong].max()) / max(float(x.detach().abs().max()), 1e-30) if bool(wrong.any()) else 0.0
+            DECISION_MARGINS.append(("sign", m))
         return torch.where(s, x, x * slope)
 
 
@@ -83,7 +94,11 @@ def _pool(t, win):
     discontinuity of the gradient, and exact ties do occur: torch.amax shares the gradient between them)."""
     if win is None:
         return t.max(dim=1)[0]
-    return (t * win.to(t.dtype)).sum(dim=1)
+    out = (t * win.to(t.dtype)).sum(dim=1)
+    with torch.no_grad():
+        gap = (t.detach().max(dim=1)[0] - out.detach()).abs().max()
+        DECISION_MARGINS.append(("pool", float(gap) / max(float(t.detach().abs().max()), 1e-30)))
+    return out
 
 
 def _embed(sd, p, groups, training, pool_idx=None, signs=None):

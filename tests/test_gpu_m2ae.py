@@ -80,8 +80,18 @@ def _compare_with_oracle(seed):
     _, _, i1, i2 = oracle_ops.chamfer(rec_cpu, group[0][1].reshape(B * G1, k1, 3).float())    # == the product's kernel, bit for bit
     decisions = {"pool_idx": pool_idx, "act_signs": act_signs, "nn_idx": (i1.long(), i2.long()),
                  "rank_target": out["matrix"].detach().float().cpu()}
+    del HR.DECISION_MARGINS[:]
     ref = HR.m2ae_pretrain_forward(sd, teacher_sd, pts, epoch, total, noise, mask=mask, decisions=decisions)
     ref["loss"].backward()
+    # the injected decisions are the oracle's own except at near-ties: a sign taken over against a pre-activation, or a
+    # pool winner below the maximum, by more than fp32 rounding of the tensor's scale would be a WRONG decision of the product
+    worst = {}
+    for kind, m in HR.DECISION_MARGINS:
+        worst[kind] = max(worst.get(kind, 0.0), m)
+    assert len(HR.DECISION_MARGINS) >= 15 and worst.get("sign", 0.0) <= 1e-4 and worst.get("pool", 0.0) <= 1e-4, worst
+    # nearest neighbours: the oracle's own choice on ITS reconstruction differs from the injected one only at near-ties
+    _, _, i1o, i2o = oracle_ops.chamfer(ref["rec"].detach().float().reshape(B * G1, k1, 3), group[0][1].reshape(B * G1, k1, 3).float())
+    assert float((i1o.long() != i1.long()).float().mean()) <= 1e-3 and float((i2o.long() != i2.long()).float().mean()) <= 1e-3
     # decision logic: the teacher's scores agree, and the oracle's mask rule applied to the PRODUCT's scores gives the product's mask
     assert _rel(out["teacher_loss_pred"], ref["teacher_loss_pred"]) <= 2e-5
     want_mask = HR.guided_mask(out["teacher_loss_pred"].detach().float().cpu(), noise, HR.CFG["mask_ratio"], epoch, total)
