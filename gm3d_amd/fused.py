@@ -301,7 +301,7 @@ def defer_wgrad(dy, x, w=None):
     read or add to the result before the region ends), the product joins the stacks' one-launch weight gradients and lands in the slot;
     elsewhere, or when the kernel does not take the shape, it is computed now."""
     reg = _ASYNC_WGRAD
-    if (reg["stream"] is not None and gemm.MULTI_WGRAD and (DEFER_HEAD_WGRAD or reg.get("defer_heads")) and w is not None and w.grad is None
+    if (reg["stream"] is not None and gemm.MULTI_WGRAD and (DEFER_HEAD_WGRAD or reg.get("defer_heads")) and w is not None and w.is_leaf and w.grad is None
             and dy.dim() == 2
             and dy.is_contiguous() and x.is_contiguous()):
         from .optim import grad_slots, ENABLE_DIRECT_WGRAD

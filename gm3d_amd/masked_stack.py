@@ -75,6 +75,9 @@ def _attn_bwd(qkv, a, da, lse, bits, B, T, H, hd, scale, dqkv):
     return dqkv
 
 
+FUSE_GELU = True          # widths 192 / 384: bias + GELU (forward) and GELU' + bias-gradient partials (backward) in the GEMM epilogues (tests flip it)
+
+
 def supported(x, blocks):
     C = x.shape[-1]
     H = blocks[0].attn.num_heads
@@ -117,8 +120,15 @@ class MaskedStackFn(torch.autograd.Function):
             a, lse = _attn_fwd(qkv, bits, B, T, H, hd, scale, A[i] if need else torch.empty(R, C, dtype=adt, device=dev))
             p = gemm.mm(a, weight_cache.get(wproj, adt))
             s2, h2, m2, r2 = _add_ln_fwd(s1, p, _c32(bproj), dp1, T, None, _c32(ln2w), _c32(ln2b), eps, adt, True, H2[i] if need else None)
-            f = gemm.mm(h2, weight_cache.get(w1, adt))
-            g = fused.bias_gelu_fwd(f, _c32(b1), adt, g=GG[i] if need else None)
+            W1 = weight_cache.get(w1, adt)
+            if FUSE_GELU and adt == torch.bfloat16 and gemm.FUSE_GELU and gemm.dma_supported(h2, W1):
+                # fc1 + bias + GELU in the product's epilogue (widths 192 / 384: N % 192 == 0, K % 64 == 0); the pre-activation is
+                # written only when a backward follows
+                f, g = gemm.linear_gelu_dma(h2, W1, _c32(b1), f_out=torch.empty(R, 4 * C, dtype=adt, device=dev) if need else None,
+                                            g_out=GG[i] if need else None, bm=gemm.dma_bm(R))
+            else:
+                f = gemm.mm(h2, W1)
+                g = fused.bias_gelu_fwd(f, _c32(b1), adt, g=GG[i] if need else None)
             y, yb, rs, s = gemm.mm(g, weight_cache.get(w2, adt)), _c32(b2), dp2, s2
             if need:
                 saved += [s1, m1, r1, qkv, lse, s2, m2, r2, f]
@@ -154,10 +164,13 @@ class MaskedStackFn(torch.autograd.Function):
         # column-sum partials of every LayerNorm site (2i: LN1 of block i, 2i+1: LN2, 2 nblk: the tail) and every GELU site
         PLN = torch.empty(2 * nblk + 1, lib.gm3d_ln_plain_partial_rows(R), 3 * C, dtype=torch.float32, device=dev)
         SLN = torch.empty(2 * nblk + 1, 3 * C, dtype=torch.float32, device=dev)
-        PGL = torch.empty(nblk, lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32, device=dev)
-        SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
         W2T, WPT, W1T, WQT = gemm.stacked_transposes(
             [[weight_cache.get(params[i * PER_BLOCK + k], adt) for i in range(nblk)] for k in (9, 3, 7, 2)])
+        # fc2's input gradient x GELU'(f + b1) + fc1's bias-gradient partials in the product's epilogue where the tile shape allows
+        dma_bwd = FUSE_GELU and adt == torch.bfloat16 and gemm.FUSE_GELU_BWD and gemm.dma_supported(gin, W2T[0])
+        bm_bwd = gemm.dma_bm(R)
+        PGL = torch.empty(nblk, (R + bm_bwd - 1) // bm_bwd if dma_bwd else lib.gm3d_gelu_partial_rows(R), 4 * C, dtype=torch.float32, device=dev)
+        SGL = torch.empty(nblk, 4 * C, dtype=torch.float32, device=dev)
         G = _add_ln_bwd(None, gin, None, None, None, None, meta["dp"][nblk - 1][1], T, DO[nblk - 1], PLN[2 * nblk], adt)
         db2 = SLN[2 * nblk, 2 * C:]
         dpos = torch.empty(R, C, dtype=adt, device=dev)
@@ -166,8 +179,11 @@ class MaskedStackFn(torch.autograd.Function):
             s1, m1, r1, qkv, lse, s2, m2, r2, f = saved[i * 9:(i + 1) * 9]
             gi = grads[i * PER_BLOCK:(i + 1) * PER_BLOCK]
             gi[10] = db2
-            dg = gemm.mm(DO[i], W2T[i])
-            fused.bias_gelu_bwd(dg, f, _c32(b1), adt, df=DF[i], partial=PGL[i])
+            if dma_bwd:
+                gemm.linear_gelu_bwd_dma(DO[i], W2T[i], f, _c32(b1), DF[i], PGL[i], bm=bm_bwd)
+            else:
+                dg = gemm.mm(DO[i], W2T[i])
+                fused.bias_gelu_bwd(dg, f, _c32(b1), adt, df=DF[i], partial=PGL[i])
             gi[8] = SGL[i]
             dh2 = gemm.mm(DF[i], W1T[i])
             G = _add_ln_bwd(dh2, G, s2, m2, r2, _c32(ln2w), meta["dp"][i][0], T, DP[i], PLN[2 * i + 1], adt)
