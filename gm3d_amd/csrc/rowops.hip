@@ -599,7 +599,9 @@ __global__ __launch_bounds__(256) void sum_few_rows_kernel(const float* __restri
 
 static inline int ln_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 512 ? 512 : g); }
 static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
-static inline int gelu_bwd_grid(int R) { return R < 512 ? R : 512; }
+// (long row streams -- the 65,536-row level 0 of the hierarchical encoder -- get four times the workgroups: at 512 a CU holds 6 waves of
+//  this kernel and the pass runs at 2.7 TB/s; the partial rows grow with the grid and are finished in one batched launch per stack)
+static inline int gelu_bwd_grid(int R) { return R < 512 ? R : (R >= 32768 ? 2048 : 512); }
 
 }  // namespace gm3d
 
@@ -742,7 +744,8 @@ extern "C" int gm3d_bias_gelu_fwd(const void* f, const float* bias, void* g, int
     if (C % 8 || C / 8 > 1024) return GM3D_EUNSUPPORTED;
     if (dtype != GM3D_F32 && dtype != GM3D_BF16) return GM3D_EINVAL;
     if (R == 0) return GM3D_OK;
-    int grid = (R + 1) / 2; grid = grid > 4096 ? 4096 : grid;
+    const int cap = R >= 32768 ? 8192 : 4096;          // one wave per workgroup at C = 384: 32 of them fit a CU
+    int grid = (R + 1) / 2; grid = grid > cap ? cap : grid;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GM3D_BF16)
         hipLaunchKernelGGL(bias_gelu_fwd_kernel<bf16_t>, dim3(grid), dim3(C / 8), 0, st, (const bf16_t*)f, bias, (bf16_t*)g, R, C);
