@@ -92,6 +92,8 @@ SIGNATURES = {
     "gm3d_gemm_tn_bf16_ws_bn_apply": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_ws_bn_stats": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_ws_stats_rows": [_i, _i, _i],
+    "gm3d_gemm_tn_bf16_ws_bn_apply_g": [_vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "gm3d_gemm_tn_bf16_ws_bn_stats_g": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_ws_set_occupancy": [_i],
     "gm3d_gemm_tn_bf16_ring96": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "gm3d_gemm_tn_bf16_dma": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],

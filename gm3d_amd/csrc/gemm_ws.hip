@@ -175,10 +175,23 @@ __global__ __launch_bounds__(64 * (NW + NL)) void gemm_tn_ws_kernel(const bf16_t
             typedef const __attribute__((address_space(4))) unsigned int* sptr_t;
 #pragma unroll
             for (int t = 0; t < TM; ++t) {
-                sptr_t tp = (sptr_t)(const void*)(bn.T + (size_t)((m0 >> 5) + t) * bn.ldt + n0 + 32 * w);
+                // pool16 (groups of 16 rows: two per tile): rows 0..15 of the tile take T row 2 g, rows 16..31 T row 2 g + 1 -- both rows
+                // come by scalar loads, the lane (= tile row r) picks its own
+                const size_t trow = pool16 ? (size_t)2 * ((m0 >> 5) + t) : (size_t)((m0 >> 5) + t);
+                sptr_t tp = (sptr_t)(const void*)(bn.T + trow * bn.ldt + n0 + 32 * w);
                 unsigned tw[16];
 #pragma unroll
                 for (int j = 0; j < 16; ++j) tw[j] = tp[j];
+                if (pool16) {
+                    sptr_t tp2 = (sptr_t)(const void*)(bn.T + (trow + 1) * bn.ldt + n0 + 32 * w);
+                    unsigned tw2[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) tw2[j] = tp2[j];
+                    if (r & 16) {
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) tw[j] = tw2[j];
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -397,7 +410,7 @@ static int ws_launch(const void* A, const void* W, const float* bias, void* C, v
         return GM3D_EUNSUPPORTED;
     }
     if (bn_mode) {                                                    // second_conv.0 with the BatchNorm that follows it (EPI 4 / 5)
-        if (M % 32 || !bn.T || bn.ldt % 4 || bn.ldt < N || ((size_t)bn.T & 7)) return GM3D_EINVAL;
+        if (M % 32 || !bn.T || bn.ldt % 4 || bn.ldt < N || ((size_t)bn.T & 7)) return GM3D_EINVAL;      // (pool16: T has M / 16 rows)
         if (K == 256 && N == 512 && bn_mode == 4) GM3D_WS_LAUNCH(4, 8, 1, 4, 1)
         if (K == 256 && N == 512 && bn_mode == 5) GM3D_WS_LAUNCH(4, 8, 1, 5, 1)
         return GM3D_EUNSUPPORTED;
@@ -461,6 +474,24 @@ extern "C" int gm3d_gemm_tn_bf16_ws_bn_stats(const void* A, const void* W, const
     gm3d::WsBn bn;
     bn.T = (const gm3d::bf16_t*)T; bn.scale = nullptr; bn.shift = nullptr; bn.partial = partial; bn.ldt = ldt; bn.slope = 0.f;
     return ws_launch(A, W, nullptr, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream, 5, bn);
+}
+
+// the two BatchNorm epilogues for groups of `group_rows` = 16 or 32 rows (T (M / group_rows, N)): Point-M2AE's level-0 groups hold 16 points
+extern "C" int gm3d_gemm_tn_bf16_ws_bn_apply_g(const void* A, const void* W, const void* T, const float* scale, const float* shift, float slope,
+                                               void* C, int M, int N, int K, int lda, int ldw, int ldt, int ldc, int group_rows,
+                                               gm3d_stream_t stream) {
+    if (!C || !T || !scale || !shift || (group_rows != 16 && group_rows != 32)) return GM3D_EINVAL;
+    gm3d::WsBn bn;
+    bn.T = (const gm3d::bf16_t*)T; bn.scale = scale; bn.shift = shift; bn.partial = nullptr; bn.ldt = ldt; bn.slope = slope;
+    return ws_launch(A, W, nullptr, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream, 4, bn, group_rows == 16);
+}
+
+extern "C" int gm3d_gemm_tn_bf16_ws_bn_stats_g(const void* A, const void* W, const void* T, void* C, float* partial, int M, int N, int K,
+                                               int lda, int ldw, int ldt, int ldc, int group_rows, gm3d_stream_t stream) {
+    if (!C || !T || !partial || (group_rows != 16 && group_rows != 32)) return GM3D_EINVAL;
+    gm3d::WsBn bn;
+    bn.T = (const gm3d::bf16_t*)T; bn.scale = nullptr; bn.shift = nullptr; bn.partial = partial; bn.ldt = ldt; bn.slope = 0.f;
+    return ws_launch(A, W, nullptr, C, nullptr, nullptr, M, N, K, lda, ldw, ldc, 0, 0, stream, 5, bn, group_rows == 16);
 }
 
 // rows of gm3d_gemm_tn_bf16_ws_bn_stats' partial buffer for this shape (0: unsupported)

@@ -145,11 +145,11 @@ class EmbedFn(torch.autograd.Function):
         # the product with the BatchNorm behind it in its epilogue (csrc/gemm_ws.hip EPI 4 / 5): train mode -> its statistics come
         # out of the product's launch (no second pass over the (rows, 512) tensor); eval mode (the EMA teacher) -> BN + ReLU applied
         # there, the product itself never reaches HBM
-        fuse_bn = K == 32 and gemm.ws_bn_supported(f, W3l, t)
+        fuse_bn = K in (16, 32) and gemm.ws_bn_supported(f, W3l, t, group_rows=K)
         y0 = st = None
         if training:
             if fuse_bn:
-                y0, part = gemm.linear_ws_bn_stats(f, W3l, t)
+                y0, part = gemm.linear_ws_bn_stats(f, W3l, t, group_rows=K)
                 st = _finish(part, part.shape[0], 2 * C3)
             else:
                 y0 = gemm.mm(f, W3l)
@@ -176,7 +176,7 @@ class EmbedFn(torch.autograd.Function):
             _launch("gm3d_group_select_maps", {"B": B, "V": Gs, "G": G}, lib.gm3d_group_select_maps, _ptr(vis), vis.stride(0), B,
                     Gs, G, _ptr(sel), _ptr(inv), _stream())
         if not training and fuse_bn and vis is None:
-            a2 = gemm.linear_ws_bn_apply(f, W3l, t, scale2, shift2)
+            a2 = gemm.linear_ws_bn_apply(f, W3l, t, scale2, shift2, group_rows=K)
         else:
             if y0 is None:
                 y0 = gemm.mm(f, W3l)

@@ -198,23 +198,24 @@ def linear_tn_ws(x, w, bias=None, out=None):
 WS_BN = True             # second_conv.0 with the BatchNorm behind it in the product's epilogue (eval: apply + ReLU; train: the statistics)
 
 
-def ws_bn_supported(x, w, t):
-    return (WS_BN and ws_supported(x, w) and x.shape[0] % 32 == 0 and t.dtype == torch.bfloat16 and t.is_contiguous()
-            and t.shape == (x.shape[0] // 32, w.shape[0]) and lib.gm3d_gemm_ws_stats_rows(x.shape[0], w.shape[0], x.shape[1]) > 0)
+def ws_bn_supported(x, w, t, group_rows=32):
+    return (WS_BN and group_rows in (16, 32) and ws_supported(x, w) and x.shape[0] % 32 == 0 and t.dtype == torch.bfloat16 and t.is_contiguous()
+            and t.shape == (x.shape[0] // group_rows, w.shape[0]) and lib.gm3d_gemm_ws_stats_rows(x.shape[0], w.shape[0], x.shape[1]) > 0)
 
 
-def linear_ws_bn_apply(x, w, t, scale, shift, slope=0.0):
+def linear_ws_bn_apply(x, w, t, scale, shift, slope=0.0, group_rows=32):
     """act((bf16(x @ w^T) + t[row // 32]) * scale + shift) in ONE launch (eval-mode BatchNorm + ReLU in the epilogue of csrc/gemm_ws.hip);
     bit-identical to linear_tn_ws followed by gm3d_bn_bcast_apply_relu."""
     M, K = x.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
-    _launch("gm3d_gemm_tn_bf16_ws_bn_apply", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_bn_apply, _ptr(x), _ptr(w), _ptr(t),
-            _ptr(scale), _ptr(shift), float(slope), _ptr(out), M, N, K, x.stride(0), w.stride(0), t.stride(0), out.stride(0), _stream())
+    _launch("gm3d_gemm_tn_bf16_ws_bn_apply", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_bn_apply_g, _ptr(x), _ptr(w), _ptr(t),
+            _ptr(scale), _ptr(shift), float(slope), _ptr(out), M, N, K, x.stride(0), w.stride(0), t.stride(0), out.stride(0), int(group_rows),
+            _stream())
     return out
 
 
-def linear_ws_bn_stats(x, w, t):
+def linear_ws_bn_stats(x, w, t, group_rows=32):
     """-> (bf16(x @ w^T), partial (rows, 2 N) f32): the product and, per workgroup, the column sums of y = product + t[row // 32] and
     y^2 (the train-mode statistics of the BatchNorm behind it; sum the rows in order)."""
     M, K = x.shape
@@ -222,8 +223,8 @@ def linear_ws_bn_stats(x, w, t):
     out = torch.empty(M, N, dtype=torch.bfloat16, device=x.device)
     rows = lib.gm3d_gemm_ws_stats_rows(M, N, K)
     part = torch.empty(rows, 2 * N, dtype=torch.float32, device=x.device)
-    _launch("gm3d_gemm_tn_bf16_ws_bn_stats", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_bn_stats, _ptr(x), _ptr(w), _ptr(t), _ptr(out),
-            _ptr(part), M, N, K, x.stride(0), w.stride(0), t.stride(0), out.stride(0), _stream())
+    _launch("gm3d_gemm_tn_bf16_ws_bn_stats", {"M": M, "N": N, "K": K}, lib.gm3d_gemm_tn_bf16_ws_bn_stats_g, _ptr(x), _ptr(w), _ptr(t), _ptr(out),
+            _ptr(part), M, N, K, x.stride(0), w.stride(0), t.stride(0), out.stride(0), int(group_rows), _stream())
     return out, part
 
 

@@ -460,6 +460,11 @@ int gm3d_gemm_tn_bf16_ws_bn_apply(const void *A, const void *W, const void *T, c
                                   int M, int N, int K, int lda, int ldw, int ldt, int ldc, gm3d_stream_t stream);
 int gm3d_gemm_tn_bf16_ws_bn_stats(const void *A, const void *W, const void *T, void *C, float *partial, int M, int N, int K, int lda,
                                   int ldw, int ldt, int ldc, gm3d_stream_t stream);
+/* ... for groups of group_rows = 16 or 32 rows (T (M / group_rows, N)): the hierarchical model's level-0 groups hold 16 points */
+int gm3d_gemm_tn_bf16_ws_bn_apply_g(const void *A, const void *W, const void *T, const float *scale, const float *shift, float slope, void *C,
+                                    int M, int N, int K, int lda, int ldw, int ldt, int ldc, int group_rows, gm3d_stream_t stream);
+int gm3d_gemm_tn_bf16_ws_bn_stats_g(const void *A, const void *W, const void *T, void *C, float *partial, int M, int N, int K, int lda,
+                                    int ldw, int ldt, int ldc, int group_rows, gm3d_stream_t stream);
 int gm3d_gemm_ws_stats_rows(int M, int N, int K);
 /* measurement knob: persistent workgroups per CU (1 or 2; two only where the LDS ring allows). Results do not depend on it. */
 int gm3d_gemm_ws_set_occupancy(int wg_per_cu);

@@ -396,6 +396,35 @@ def test_gemm_weight_stationary_pool_epilogue_groups_of_16(groups, K, N, after, 
     assert int(arg.max()) <= 15
 
 
+@pytest.mark.parametrize("groups", [4096, 65536, 2062])
+def test_gemm_weight_stationary_batchnorm_epilogues_groups_of_16(groups):
+    """the same two epilogues with 16 rows per group (two groups per 32-row tile, each lane picks its group's row of T): Point-M2AE's
+    level-0 embed (Point-M2AE_SA3D/cfgs/config_Point_M2AE.yaml:60: 16 points per group)"""
+    from gm3d_amd import gemm
+    from gm3d_amd._capi import lib, check
+    from gm3d_amd.ops import _ptr, _stream
+    M, K, N = groups * 16, 256, 512
+    g = torch.Generator(device="cuda").manual_seed(groups)
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    t = torch.randn(groups, N, device="cuda", generator=g).bfloat16()
+    scale = torch.randn(N, device="cuda", generator=g)
+    shift = torch.randn(N, device="cuda", generator=g) * 0.3
+    assert gemm.ws_bn_supported(x, w, t, group_rows=16) and not gemm.ws_bn_supported(x, w, t)
+    y0 = gemm.linear_tn(x, w)
+    want = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    check(lib.gm3d_bn_bcast_apply_relu(_ptr(y0), _ptr(t), _ptr(scale), _ptr(shift), _ptr(want), groups, 16, N, 0.0, 1, _stream()), "apply")
+    got = gemm.linear_ws_bn_apply(x, w, t, scale, shift, group_rows=16)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    prod, part = gemm.linear_ws_bn_stats(x, w, t, group_rows=16)
+    assert torch.equal(prod, y0)
+    y = (y0.double().view(groups, 16, N) + t.double()[:, None, :]).view(M, N)
+    s1, s2 = y.sum(0), (y * y).sum(0)
+    st = part.double().sum(0)
+    assert float((st[:N] - s1).abs().max()) <= 2e-6 * float(y.abs().sum(0).max())
+    assert float((st[N:] - s2).abs().max()) <= 2e-6 * float(s2.max())
+
+
 @pytest.mark.parametrize("groups", [2048, 8192, 1031])
 def test_gemm_weight_stationary_batchnorm_epilogues(groups):
     """second_conv.0 (256 -> 512) with the BatchNorm behind it inside the product's launch (csrc/gemm_ws.hip EPI 4 / 5):
