@@ -12,8 +12,15 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
+ap.add_argument("--set", action="append", default=[], metavar="mod.ATTR=value",
+                help="flip a module switch of gm3d_amd for a same-box A/B (e.g. --set gemm.WS_BN=False --set point_m2ae.VISIBLE_FIRST=False)")
 ap.add_argument("--narrow-attn", action="store_true", help="A/B: four tiles per workgroup in the masked attention kernels (the round-3 form)")
 a = ap.parse_args()
+import importlib
+for item in a.set:
+    name, val = item.split("=")
+    mod, attr = name.rsplit(".", 1)
+    setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
 if a.narrow_attn:
     from gm3d_amd._capi import lib as _lib
     _lib.gm3d_attention_masked_set_wide(0)
