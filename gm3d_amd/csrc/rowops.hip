@@ -242,7 +242,10 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
     // dh == nullptr: no LayerNorm behind the sum (the tail of a block stack) -- dx = gin, nothing of x / mean / rstd / gamma is read.
     // acc (optional): the running sum of dx over the sites that share an addend (the positional embedding, re-added in front of
     // every block): acc_mode 1 acc = dx, 2 acc += dx -- one rounding to T per site, like an accumulation of T tensors
-    __shared__ float red[8][3 * 512];
+    // (sized by the width class: with the former [8][3 * 512] = 48 KiB for every width a CU held 3 workgroups = 12 waves of this kernel,
+    //  and the 96-wide pass over 65,536 rows ran at 2 TB/s)
+    constexpr int RW = 128 * NQ;
+    __shared__ float red[8][3 * RW];
     const int lane = threadIdx.x & 63, hl = lane & 31, half = lane >> 5, slot = (threadIdx.x >> 6) * 2 + half;
     const int wbase = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
     const int stride = gridDim.x * 8;
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
         const int c = 4 * hl + 128 * i;
         if (c < C) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[i][j]; red[slot][512 + c + j] = sb[i][j]; red[slot][1024 + c + j] = sy[i][j]; }
+            for (int j = 0; j < 4; ++j) { red[slot][c + j] = sg[i][j]; red[slot][RW + c + j] = sb[i][j]; red[slot][2 * RW + c + j] = sy[i][j]; }
         }
     }
     __syncthreads();
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(256) void ln_plain_bwd_kernel(const T* __restrict__
         const int which = t / C, c = t - which * C;
         float acc = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) acc += red[k][which * 512 + c];
+        for (int k = 0; k < 8; ++k) acc += red[k][which * RW + c];
         partial[((size_t)blockIdx.x * nsum + which) * C + c] = acc;
     }
 }
@@ -597,7 +600,9 @@ __global__ __launch_bounds__(256) void sum_few_rows_kernel(const float* __restri
     }
 }
 
-static inline int ln_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 512 ? 512 : g); }
+// (long row streams -- the hierarchical encoder's 65,536-row level 0 -- get four times the workgroups; every workgroup writes one row of
+//  the partial sums, which the stacks finish in one batched launch)
+static inline int ln_grid(int R) { int g = (R + 7) / 8; const int cap = R >= 32768 ? 2048 : 512; return g < 1 ? 1 : (g > cap ? cap : g); }
 static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
 // (long row streams -- the 65,536-row level 0 of the hierarchical encoder -- get four times the workgroups: at 512 a CU holds 6 waves of
 //  this kernel and the pass runs at 2.7 TB/s; the partial rows grow with the grid and are finished in one batched launch per stack)

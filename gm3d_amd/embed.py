@@ -148,7 +148,9 @@ class EmbedFn(torch.autograd.Function):
         fuse_bn = K in (16, 32) and gemm.ws_bn_supported(f, W3l, t, group_rows=K)
         y0 = st = None
         if training:
-            if fuse_bn:
+            # (groups of 16 rows: the statistics epilogue measured SLOWER than product + pass -- 711 vs 355 + 245 us at 1,048,576 rows,
+            #  tools/m2ae_gemm_shapes.py -- so only the eval-mode apply epilogue is used there: 654 vs 355 + 388)
+            if fuse_bn and (K == 32 or gemm.WS_BN_STATS16):
                 y0, part = gemm.linear_ws_bn_stats(f, W3l, t, group_rows=K)
                 st = _finish(part, part.shape[0], 2 * C3)
             else:

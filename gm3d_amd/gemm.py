@@ -198,6 +198,9 @@ def linear_tn_ws(x, w, bias=None, out=None):
 WS_BN = True             # second_conv.0 with the BatchNorm behind it in the product's epilogue (eval: apply + ReLU; train: the statistics)
 
 
+WS_BN_STATS16 = False    # the train-mode statistics epilogue for 16-row groups: slower than the separate pass (see embed.py); kept as a tested entry point
+
+
 def ws_bn_supported(x, w, t, group_rows=32):
     return (WS_BN and group_rows in (16, 32) and ws_supported(x, w) and x.shape[0] % 32 == 0 and t.dtype == torch.bfloat16 and t.is_contiguous()
             and t.shape == (x.shape[0] // group_rows, w.shape[0]) and lib.gm3d_gemm_ws_stats_rows(x.shape[0], w.shape[0], x.shape[1]) > 0)
