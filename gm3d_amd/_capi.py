@@ -31,6 +31,7 @@ SIGNATURES = {
     "gm3d_attention_qkv_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _i, _vp],
     "gm3d_attention_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "gm3d_ln_plain_partial_rows": [_i],
+    "gm3d_ln_set_grid_cap": [_i],
     "gm3d_ln_plain_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_ln_plain_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "gm3d_residual_ln_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

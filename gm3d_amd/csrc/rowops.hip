@@ -602,13 +602,24 @@ __global__ __launch_bounds__(256) void sum_few_rows_kernel(const float* __restri
 
 // (long row streams -- the hierarchical encoder's 65,536-row level 0 -- get four times the workgroups; every workgroup writes one row of
 //  the partial sums, which the stacks finish in one batched launch)
-static inline int ln_grid(int R) { int g = (R + 7) / 8; const int cap = R >= 32768 ? 2048 : 512; return g < 1 ? 1 : (g > cap ? cap : g); }
+static int LN_GRID_CAP_MID = 512;      // measurement knob (gm3d_ln_set_grid_cap): the cap for 8192 <= R < 32768
+static inline int ln_grid(int R) {
+    int g = (R + 7) / 8;
+    const int cap = R >= 32768 ? 2048 : (R >= 8192 ? LN_GRID_CAP_MID : 512);
+    return g < 1 ? 1 : (g > cap ? cap : g);
+}
 static inline int ln_fwd_grid(int R) { int g = (R + 7) / 8; return g < 1 ? 1 : (g > 4096 ? 4096 : g); }   // no partial rows: one row per half-wave
 // (long row streams -- the 65,536-row level 0 of the hierarchical encoder -- get four times the workgroups: at 512 a CU holds 6 waves of
 //  this kernel and the pass runs at 2.7 TB/s; the partial rows grow with the grid and are finished in one batched launch per stack)
 static inline int gelu_bwd_grid(int R) { return R < 512 ? R : (R >= 32768 ? 2048 : 512); }
 
 }  // namespace gm3d
+
+extern "C" int gm3d_ln_set_grid_cap(int cap) {
+    if (cap < 64 || cap > 4096) return GM3D_EINVAL;
+    gm3d::LN_GRID_CAP_MID = cap;
+    return GM3D_OK;
+}
 
 extern "C" int gm3d_ln_partial_rows(int R) { return R < 1 ? 0 : gm3d::ln_grid(R); }
 extern "C" int gm3d_gelu_partial_rows(int R) { return R < 1 ? 0 : gm3d::gelu_bwd_grid(R); }

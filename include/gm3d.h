@@ -140,6 +140,8 @@ int gm3d_patch_chamfer_loss_bwd_full(const void *pred, long long pred_bstride, c
  * partial (gm3d_ln_plain_partial_rows(R), 2, C) f32: [.][0] = per-block sums of dh * xhat (dgamma), [.][1] = of dh (dbeta), to be
  * finished by gm3d_colsum_finish over 2*C columns. */
 int gm3d_ln_plain_partial_rows(int R);
+/* measurement knob: workgroup cap (= rows of partial sums) of the LayerNorm backward kernels for 8192 <= R < 32768 (default 512) */
+int gm3d_ln_set_grid_cap(int cap);
 int gm3d_ln_plain_fwd(const void *x, const float *gamma, const float *beta, float eps, void *h, float *mean, float *rstd, int R,
                       int C, int dtype, gm3d_stream_t stream);
 int gm3d_ln_plain_bwd(const void *dh, const void *x, const float *mean, const float *rstd, const float *gamma, void *dx,

@@ -8,6 +8,13 @@ cut = args.index("--") if "--" in args else len(args)
 for item in args[:cut]:
     name, val = item.split("=")
     mod, attr = name.rsplit(".", 1)
+    if mod == "capi":          # capi.gm3d_ln_set_grid_cap=1024 -> call a process-wide knob of the C ABI
+        import torch
+        torch.cuda.init()           # (the HIP runtime first, as in bench.py: the library's first launch otherwise reports a stale error)
+        torch.zeros(1, device="cuda")
+        from gm3d_amd._capi import lib
+        assert getattr(lib, attr)(int(eval(val))) == 0
+        continue
     setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
 sys.argv = [os.path.join(ROOT, "bench.py")] + args[cut + 1:]
 runpy.run_path(sys.argv[0], run_name="__main__")
