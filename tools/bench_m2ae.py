@@ -20,6 +20,10 @@ import importlib
 for item in a.set:
     name, val = item.split("=")
     mod, attr = name.rsplit(".", 1)
+    if mod == "capi":          # --set capi.gm3d_gemm_ws_set_tm2=1: a process-wide knob of the C ABI
+        from gm3d_amd._capi import lib as _l
+        assert getattr(_l, attr)(int(eval(val))) == 0
+        continue
     setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
 if a.narrow_attn:
     from gm3d_amd._capi import lib as _lib
