@@ -479,14 +479,29 @@ class PointM2AE(nn.Module):
         return {"Chamfer_mean": loss, "matrix": matrix, "per_token": cd}
 
 
-def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, group=None):
+def group_stage(divider, pts, augment=True):
+    """Everything of an iteration that depends on the clouds alone -- augmentation (P/engine_pretrain.py:80), the three FPS + KNN levels,
+    the token propagation's 3-NN lists -- -> (augmented clouds, (neighbourhoods, centres, idxs), (prop_idx, prop_w)).  No parameter is
+    read: GraphedM2AEStep replays this for the NEXT batch on a second stream while the current batch trains."""
+    from . import engine_pretrain as E
+    with torch.no_grad():
+        if augment:
+            pts = E.train_transforms(pts)
+        group = divider(pts)
+        prop = TokenPropagation.neighbours(group[1][1], group[1][2])
+    return pts, group, prop
+
+
+def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, group=None, prop=None):
     """One GeoMask3D iteration's forward on the hierarchical model: the EMA teacher scores the 64 coarsest tokens with nothing
     masked, the guided mask (P/models_mae_learn_loss.py:744-784 with this model's mask ratio) hides the hardest ones, the student
-    reconstructs and predicts its own per-token loss.  -> dict with `loss`, `loss_chfr`, `loss_learn`, `mask`."""
+    reconstructs and predicts its own per-token loss.  -> dict with `loss`, `loss_chfr`, `loss_learn`, `mask`.
+    group / prop: the results of group_stage when the caller has them already."""
     raw = model.module if hasattr(model, "module") else model
     with torch.no_grad():
         group = group if group is not None else teacher.group_divider(pts)
-        prop = TokenPropagation.neighbours(group[1][1], group[1][2])     # shared by the teacher's and the student's up-block
+        if prop is None:
+            prop = TokenPropagation.neighbours(group[1][1], group[1][2])     # shared by the teacher's and the student's up-block
         t = teacher(pts, mask=None, group=group, prop=prop)
         mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
                                                       total_epoch=total_epoch, noise=mask_noise)
@@ -501,16 +516,19 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
             "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"], "rec": out["rec"]}
 
 
-def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None, augment=True):
+def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None, augment=True, staged=None):
     """augment -> teacher -> mask -> student -> losses -> backward -> clip(5) -> AdamW -> EMA (the loop body of
-    P/engine_pretrain.py:77-212 around this model)."""
+    P/engine_pretrain.py:77-212 around this model).  staged = group_stage(...)'s result for these clouds (then `pts`, `augment` are unused)."""
     from . import engine_pretrain as E
     from contextlib import nullcontext
-    if augment:
+    group = prop = None
+    if staged is not None:
+        pts, group, prop = staged
+    elif augment:
         pts = E.train_transforms(pts)
     amp = torch.autocast("cuda", dtype=torch.bfloat16) if getattr(args, "bf16", False) else nullcontext()
     with amp:
-        out = pretrain_forward(model, model_ema.ema, pts, epoch, args.epochs, mask_noise=mask_noise)
+        out = pretrain_forward(model, model_ema.ema, pts, epoch, args.epochs, mask_noise=mask_noise, group=group, prop=prop)
     optimizer.zero_grad(set_to_none=True)
     if DEFER_WGRADS and pts.is_cuda:
         from . import fused
@@ -520,3 +538,73 @@ def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None
         out["loss"].backward()
     out["grad_norm"] = E.step_update(model, model_ema, optimizer)
     return {k: (v.detach() if torch.is_tensor(v) else v) for k, v in out.items()}
+
+
+class GraphedM2AEStep:
+    """The Point-M2AE + GeoMask3D step as hipGraph replays, with the NEXT batch's grouping beside the current batch's training.
+
+    Two graphs: `group_graph` = group_stage (augmentation, three FPS + KNN levels, 3-NN lists: ~1.3 ms of one-workgroup-per-cloud
+    chains that use half the CUs and no parameter) on a second stream; `train_graph` = everything else (teacher, mask, student, losses,
+    backward, clip + AdamW + EMA).  A call copies the staged results into the training graph's own inputs (one multi-tensor copy),
+    queues the next batch's grouping on the side stream and replays the training graph -- what engine_finetune.GraphedFinetuneStep does
+    for its point sampling.  Without `next_pts` the grouping of a batch runs right before its training (same results: the stages read
+    and write disjoint state; with augmentation on, the random draws of a batch are taken when its grouping is queued).
+    `epoch` is baked into the captures (mask schedule), like GraphedPretrainStep."""
+
+    def __init__(self, model, model_ema, optimizer, args, example, epoch, augment=True, inject_mask_noise=False, warmup_iters=2):
+        from . import streams
+        self.model, self.ema, self.opt, self.args, self.epoch, self.augment = model, model_ema, optimizer, args, epoch, augment
+        raw = model.module if hasattr(model, "module") else model
+        dev = example.device
+        self.static_in = example.clone()
+        self.static_noise = torch.rand(example.shape[0], raw.num_group, device=dev) if inject_mask_noise else None
+        self.side = torch.cuda.Stream(device=dev)
+        self._ready, self._staged = torch.cuda.Event(), False
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup_iters):
+                pretrain_step(model, model_ema, optimizer, self.static_in.clone(), epoch, args, mask_noise=self.static_noise, augment=augment)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        divider = model_ema.ema.group_divider
+        self.group_graph = torch.cuda.CUDAGraph()
+        with streams.capture(self.group_graph, stream=self.side):
+            pts, group, prop = group_stage(divider, self.static_in, augment=augment)
+            self._stage_out = [pts] + list(group[0]) + list(group[1]) + list(group[2]) + list(prop)
+        torch.cuda.synchronize()
+        self.group_graph.replay()            # real values for the capture below (a capture executes nothing)
+        torch.cuda.synchronize()
+        self._train_in = [t.clone() for t in self._stage_out]
+        n = len(group[0])
+        ti = self._train_in
+        staged = (ti[0], (ti[1:1 + n], ti[1 + n:1 + 2 * n], ti[1 + 2 * n:1 + 3 * n]), (ti[1 + 3 * n], ti[2 + 3 * n]))
+        self.train_graph = torch.cuda.CUDAGraph()
+        with streams.capture(self.train_graph):
+            self.out = pretrain_step(model, model_ema, optimizer, None, epoch, args, mask_noise=self.static_noise, staged=staged)
+        torch.cuda.synchronize()
+
+    def _enqueue_grouping(self, pts):
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())       # after the copy that consumed the previous staged batch, and after pts' producer
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ev)
+            self.static_in.copy_(pts, non_blocking=True)
+            pts.record_stream(self.side)
+            self.group_graph.replay()
+            self._ready.record(self.side)
+        self._staged = True
+
+    def __call__(self, pts, mask_noise=None, next_pts=None):
+        main = torch.cuda.current_stream()
+        if not self._staged:                          # first call, or no look-ahead was given last time: group this batch now
+            self._enqueue_grouping(pts)
+        main.wait_event(self._ready)
+        torch._foreach_copy_(self._train_in, self._stage_out)
+        if self.static_noise is not None and mask_noise is not None:
+            self.static_noise.copy_(mask_noise, non_blocking=True)
+        self._staged = False
+        if next_pts is not None:                      # queued BEFORE the training graph so that the two run side by side
+            self._enqueue_grouping(next_pts)
+        self.train_graph.replay()
+        return self.out

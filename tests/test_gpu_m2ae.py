@@ -277,3 +277,38 @@ def test_fused_block_stack_equals_per_op_blocks(bf16):
     assert rel(res[True][1], res[False][1]) <= 2 * tol and rel(res[True][2], res[False][2]) <= 2 * tol
     for k, v in res[False][3].items():
         assert rel(res[True][3][k], v) <= (4e-2 if bf16 else 5e-5), k
+
+
+def test_graphed_step_with_staged_grouping_equals_eager():
+    """point_m2ae.GraphedM2AEStep: the training graph + the next batch's grouping graph on a second stream, fed with look-ahead
+    (next_pts) and without -- a twin stepping eagerly on the same inputs sees EQUAL losses, weights and teacher (augmentation and
+    DropPath off, mask noise injected: the random draws of the two orders are not the same stream)."""
+    from types import SimpleNamespace
+    from gm3d_amd import engine_pretrain as E
+    from gm3d_amd import point_m2ae as P
+    B = 16
+    args = SimpleNamespace(bf16=True, epochs=300)
+    pool = [clouds.gaussian(B, 2048, seed=700 + i).cuda() for i in range(6)]
+    noise = [torch.rand(B, 64, generator=torch.Generator().manual_seed(60 + i)).cuda() for i in range(6)]
+    twins = []
+    for _ in range(2):
+        torch.manual_seed(13)
+        m = P.PointM2AE().cuda().train()
+        for mod in m.modules():
+            if hasattr(mod, "drop_prob"):
+                mod.drop_prob = 0.0
+        ema = E.ModelEma(m, 0.999)
+        twins.append((m, ema, E.build_optimizer(m, lr=1e-3, flat=True, model_ema=ema)))
+    (ma, ea, oa), (mb, eb, ob) = twins
+    for _ in range(2):          # the eager iterations before a capture, on both twins with the same inputs
+        P.pretrain_step(ma, ea, oa, pool[0].clone(), 100, args, mask_noise=noise[0], augment=False)
+        P.pretrain_step(mb, eb, ob, pool[0].clone(), 100, args, mask_noise=noise[0], augment=False)
+    g = P.GraphedM2AEStep(mb, eb, ob, args, pool[0], 100, augment=False, inject_mask_noise=True, warmup_iters=0)
+    for i in range(1, 6):
+        want = P.pretrain_step(ma, ea, oa, pool[i].clone(), 100, args, mask_noise=noise[i], augment=False)
+        nxt = pool[i + 1] if (i + 1 < 6 and i % 2 == 1) else None          # with and without look-ahead
+        got = g(pool[i], mask_noise=noise[i], next_pts=nxt)
+        torch.cuda.synchronize()
+        for k in ("loss_chfr", "loss_learn", "grad_norm"):
+            assert float(want[k]) == float(got[k]), (i, k, float(want[k]), float(got[k]))
+    assert torch.equal(oa.P, ob.P) and torch.equal(oa.E, ob.E)
