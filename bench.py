@@ -318,11 +318,22 @@ def secondary(device, replays=10):
         opt = E.build_optimizer(model, lr=1e-3, flat=True, model_ema=ema)
         ma = SimpleNamespace(bf16=True, epochs=300)
         pool = [make_clouds(B, 2048, 100 + i, device) for i in range(3)]
-        # two graphs: the training step, and the NEXT batch's augmentation + grouping replayed beside it on a second stream
-        # (point_m2ae.GraphedM2AEStep; the fine-tune leg stages its point sampling the same way)
-        g = P.GraphedM2AEStep(model, ema, opt, ma, pool[0], 100)
-        r = timed(lambda i: g(pool[i % 3], next_pts=pool[(i + 1) % 3]), B)
-        r["execution"] = "hipGraph replay (training graph + next batch's grouping graph on a second stream)"
+        # the whole step as ONE graph (point_m2ae.GraphedM2AEStep -- the next batch's grouping on a second stream -- measures the same:
+        # profiles/NEGATIVE_RESULTS.md, round 4)
+        for i in range(2):
+            P.pretrain_step(model, ema, opt, pool[i].clone(), 100, ma)
+        torch.cuda.synchronize()
+        static_in = pool[0].clone()
+        from gm3d_amd import streams
+        g = torch.cuda.CUDAGraph()
+        with streams.capture(g):
+            res = P.pretrain_step(model, ema, opt, static_in, 100, ma)
+
+        def step(i):
+            static_in.copy_(pool[i % 3])
+            g.replay()
+            return res
+        r = timed(step, B)
         r["workload"] = "Point-M2AE+GM3D pretrain step: B=128 clouds of 2048 points, G=512/256/64, k=16/8/8, dims 96/192/384"
         # roofline of this step's dominant hand-written kernel (HIP-event brackets over two eager steps right after the replays; the
         # counters behind `traffic` are the committed --pmc passes over tools/bench_m2ae.py)

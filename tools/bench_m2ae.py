@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=128)
 ap.add_argument("--steps", type=int, default=20)
 ap.add_argument("--warmup", type=int, default=5)
-ap.add_argument("--one-graph", action="store_true", help="A/B: the whole step as one graph, grouping in line (no look-ahead)")
+ap.add_argument("--staged", action="store_true", help="A/B: training graph + the next batch's grouping graph on a second stream")
 ap.add_argument("--set", action="append", default=[], metavar="mod.ATTR=value",
                 help="flip a module switch of gm3d_amd for a same-box A/B (e.g. --set gemm.WS_BN=False --set point_m2ae.VISIBLE_FIRST=False)")
 ap.add_argument("--narrow-attn", action="store_true", help="A/B: four tiles per workgroup in the masked attention kernels (the round-3 form)")
@@ -54,7 +54,7 @@ line = {"metric": "point-clouds/sec Point-M2AE+GM3D pretrain step (N=2048, G=512
         "dtype": "bf16", "data": "synthetic", "batch": a.batch, "eager_ms_per_step": t_eager * 1e3, "eager_clouds_per_s": a.batch / t_eager,
         "loss": float(o["loss"])}
 try:
-    if a.one_graph:           # the whole step as ONE graph (grouping in line)
+    if not a.staged:          # the whole step as ONE graph (grouping in line): what bench.py's secondary leg runs
         static_in = pool[0].clone()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
@@ -64,7 +64,7 @@ try:
             static_in.copy_(pool[i % 4])
             g.replay()
             return out
-    else:                     # training graph + the next batch's grouping graph on a second stream (what bench.py's secondary leg runs)
+    else:                     # training graph + the next batch's grouping graph on a second stream (point_m2ae.GraphedM2AEStep)
         gs = P.GraphedM2AEStep(model, ema, opt, args, pool[0], 100)
         replay = lambda i: gs(pool[i % 4], next_pts=pool[(i + 1) % 4])
     run(replay, a.warmup)
