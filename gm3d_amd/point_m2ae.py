@@ -512,8 +512,14 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
     target = M.take(lo["matrix"].detach().float(), mask_ids)
     from . import heads
     loss_learn = heads.rank_loss(pred, target)
-    return {"loss": lo["Chamfer_mean"] + loss_learn, "loss_chfr": lo["Chamfer_mean"], "loss_learn": loss_learn, "mask": masked,
-            "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"], "rec": out["rec"]}
+    res = {"loss": lo["Chamfer_mean"] + loss_learn, "loss_chfr": lo["Chamfer_mean"], "loss_learn": loss_learn, "mask": masked,
+           "teacher_loss_pred": t["loss_pred"], "matrix": lo["matrix"], "rec": out["rec"]}
+    if pts.is_cuda and VISIBLE_FIRST:
+        # (1,) int32 device flag, non-zero if a cloud ever had more visible tokens than the static bound of the visible-first order
+        # (tokens were then dropped): read it where the finite-loss guard is read, never inside a step
+        from . import masked_stack
+        res["vis_overflow"] = masked_stack.overflow_flag(pts.device)
+    return res
 
 
 def pretrain_step(model, model_ema, optimizer, pts, epoch, args, mask_noise=None, augment=True, staged=None):

@@ -204,6 +204,7 @@ def test_m2ae_step_replays_like_eager_at_full_batch():
             assert a == b, (i, k, a, b)
         assert bool(torch.isfinite(ob.P).all()) and bool(torch.isfinite(ob.E).all())
     assert torch.equal(oa.P, ob.P) and torch.equal(oa.E, ob.E)
+    assert int(out["vis_overflow"]) == 0          # the static bounds of the visible-first order held on every replayed batch
 
 
 def test_m2ae_bf16_mode_tracks_fp32_mode():
