@@ -176,6 +176,7 @@ def ws_supported(x, w, pool=False):
             and bool(lib.gm3d_gemm_ws_supported(w.shape[0], w.shape[1], int(pool))))
 
 
+DMA192_BM64 = True       # ... with 64-row tiles while 128-row tiles would not give every CU two workgroups (one column tile at N = 192)
 DMA192_RAGGED = True     # N % 192 == 0 but N % 128 != 0 (192, 576) at K % 64 == 0: 192-column double-buffer tiles (A/B: tools/ab_m2ae.sh)
 WS_RAGGED = True         # ... and the ragged-K members (K = 96 / 288; N = 96 / 288 / 384): 25-28 us on the tiled kernels at 65,536 rows
 
@@ -285,7 +286,8 @@ def mm(x, w, bias=None, out=None):
             and x.shape[0] >= 8192 and (out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0))):
         # N = 192 / 576 (the 192-wide level of the hierarchical model): whole 192-column tiles on the LDS-DMA double-buffer kernel instead of
         # the ring kernel's 128-column tiles with a ragged second one (a quarter of its MFMA and LDS work wasted)
-        return linear_tn_dmaw(x, w, bias, out, bm=dma_bm(x.shape[0]), bn=192)
+        tiles128 = -(-x.shape[0] // 128) * (w.shape[0] // 192)
+        return linear_tn_dmaw(x, w, bias, out, bm=64 if (DMA192_BM64 and tiles128 < 512) else dma_bm(x.shape[0]), bn=192)
     if how == "lib" and ragged_supported(x, w) and (out is None or (out.stride(1) == 1 and out.stride(0) % 8 == 0)):
         # a ragged last column tile alone (K a multiple of the 64-column stage): the ring kernel; a ragged K as well: csrc/gemm.hip
         if w.shape[1] % 64 == 0:
