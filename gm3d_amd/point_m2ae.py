@@ -47,7 +47,6 @@ POOL_TAPS = None          # tests set this to a list: every max-pool of a grad-e
 FUSED_EMBED_DEEP = True   # levels 1-2 token embeds: BatchNorm on the streaming kernels, no concatenation (bf16 mode)
 FUSED_PROPAGATION = True  # token propagation: 3-NN interpolation + concatenation as one launch (heads.Interp3Fn), deterministic backward
 DEFER_WGRADS = True       # pretrain_step: weight gradients of the layers outside the block stacks as one launch at the end of backward
-TEACHER_SPLIT = True      # pretrain_forward: the EMA teacher's pass as two half-batch chains on two streams (same results: eval mode, no_grad)
 STACK_NODE = True         # a block stack as ONE autograd node (masked_stack.MaskedStackFn): the weight gradients of all its blocks in one
 #                           launch, one column-sum finish per kind, one transposing launch; FUSED_BLOCKS' per-op nodes are the cross-check
 VISIBLE_FIRST = True      # student pass: every level's stack runs on the visible tokens moved to the front of the cloud, cut to the
@@ -312,16 +311,6 @@ class TokenPropagation(nn.Module):
         return y.view(B, N, -1)
 
 
-_side_streams = {}
-
-
-def _side_stream(device):
-    key = (device.type, device.index)
-    if key not in _side_streams:
-        _side_streams[key] = torch.cuda.Stream(device=device)
-    return _side_streams[key]
-
-
 def _pos_mlp(dim):
     return nn.Sequential(Linear(3, dim), nn.GELU(), Linear(dim, dim))
 
@@ -513,28 +502,7 @@ def pretrain_forward(model, teacher, pts, epoch, total_epoch, mask_noise=None, g
         group = group if group is not None else teacher.group_divider(pts)
         if prop is None:
             prop = TokenPropagation.neighbours(group[1][1], group[1][2])     # shared by the teacher's and the student's up-block
-        B = pts.shape[0]
-        if TEACHER_SPLIT and pts.is_cuda and B % 2 == 0 and B >= 32 and not teacher.training:
-            # The EMA teacher runs in eval mode under no_grad: nothing couples the clouds of a batch.  Its deeper levels are chains of
-            # small launches (12,288 .. 32,768 rows) that fill the chip about half: the two half-batches run as parallel chains on
-            # two streams (parallel branches of a captured graph), like the north-star teacher's stacks (fused.NOGRAD_SPLIT).
-            from . import streams
-            h = B // 2
-            cut = lambda lst, a, b: [t_[a:b] for t_ in lst]
-            side = _side_stream(pts.device)
-            streams.fork(side, who="point_m2ae.pretrain_forward: second half-batch of the teacher's pass (TEACHER_SPLIT)")
-            for t_ in [pts] + list(group[0]) + list(group[1]) + list(group[2]) + list(prop):
-                t_.record_stream(side)
-            with torch.cuda.stream(side):
-                t1 = teacher(pts[h:], mask=None, group=(cut(group[0], h, B), cut(group[1], h, B), cut(group[2], h, B)),
-                             prop=(prop[0][h:], prop[1][h:]))
-            t0 = teacher(pts[:h], mask=None, group=(cut(group[0], 0, h), cut(group[1], 0, h), cut(group[2], 0, h)),
-                         prop=(prop[0][:h], prop[1][:h]))
-            streams.join(side)
-            t1["loss_pred"].record_stream(torch.cuda.current_stream())
-            t = {"loss_pred": torch.cat([t0["loss_pred"], t1["loss_pred"]], dim=0)}
-        else:
-            t = teacher(pts, mask=None, group=group, prop=prop)
+        t = teacher(pts, mask=None, group=group, prop=prop)
         mask, vis_ids, mask_ids = M.generate_mask_ids(t["loss_pred"], mask_ratio=raw.mask_ratio, guide=True, epoch=epoch,
                                                       total_epoch=total_epoch, noise=mask_noise)
         masked = mask.to(torch.bool)

@@ -313,35 +313,3 @@ def test_graphed_step_with_staged_grouping_equals_eager():
         for k in ("loss_chfr", "loss_learn", "grad_norm"):
             assert float(want[k]) == float(got[k]), (i, k, float(want[k]), float(got[k]))
     assert torch.equal(oa.P, ob.P) and torch.equal(oa.E, ob.E)
-
-
-@pytest.mark.parametrize("bf16", [False, True])
-def test_teacher_as_two_half_batch_chains_gives_the_same_scores(bf16):
-    """point_m2ae.TEACHER_SPLIT: the EMA teacher (eval mode, no_grad) on two half-batches on two streams -- nothing couples the clouds
-    of a batch, so its scores, the guided mask and everything downstream are EQUAL to the one-chain pass."""
-    from contextlib import nullcontext
-    from gm3d_amd import engine_pretrain as E
-    from gm3d_amd import point_m2ae as P
-    torch.manual_seed(3)
-    model = P.PointM2AE().cuda().train()
-    for mod in model.modules():
-        if hasattr(mod, "drop_prob"):
-            mod.drop_prob = 0.0
-    ema = E.ModelEma(model, 0.999)
-    pts = clouds.gaussian(32, 2048, seed=5).cuda()
-    noise = torch.rand(32, 64, generator=torch.Generator().manual_seed(2)).cuda()
-    res = {}
-    was = P.TEACHER_SPLIT
-    try:
-        for split in (True, False):
-            P.TEACHER_SPLIT = split
-            sd = {k: v.clone() for k, v in model.state_dict().items()}
-            with torch.no_grad(), (torch.autocast("cuda", dtype=torch.bfloat16) if bf16 else nullcontext()):
-                o = P.pretrain_forward(model, ema.ema, pts, 100, 300, mask_noise=noise)
-            torch.cuda.synchronize()
-            res[split] = (o["teacher_loss_pred"].float().clone(), o["mask"].clone(), o["loss_chfr"].float().clone())
-            model.load_state_dict(sd)
-    finally:
-        P.TEACHER_SPLIT = was
-    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
-    assert float(res[True][2]) == float(res[False][2])
