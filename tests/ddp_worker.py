@@ -95,7 +95,59 @@ def run(rank, world, port, out, B=4, steps=3):
     torch.save({"params": opt.P.cpu(), "ema": opt.E.cpu(), "stats": {k: float(v) for k, v in stats.items()}},
                os.path.join(out, "epoch_rank%d.pt" % rank))
     dist.barrier()
+    full_size_leg(rank, world, out, E, M, clouds, args)
+    dist.barrier()
     dist.destroy_process_group()
+
+
+def full_size_leg(rank, world, out, E, M, clouds, args, B=128, steps=3):
+    """BASELINE config #3 at its per-rank size: B = 128 clouds per rank, the captured four-graph SegmentedDDPStep, two ranks.  The flat
+    buffers are 147 MB each: the comparisons are made HERE (the ranks exchange their eagerly computed shard gradients over gloo) and
+    only verdicts, hashes and losses are written."""
+    import hashlib
+    import torch
+    import torch.distributed as dist
+    digest = lambda t: hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+    data = [clouds.gaussian(B * world, 1024, 900 + i) for i in range(steps + 1)]
+    noise = [torch.rand(B * world, 64, generator=torch.Generator().manual_seed(950 + i)) for i in range(steps + 1)]
+    ids = E.shard_for_rank(B * world, rank, world, shuffle=False)
+    torch.manual_seed(100 + rank)
+    m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, M.DropPath):
+            mod.drop_prob = 0.0
+    ema = E.ModelEma(m, 0.999)
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment)
+    E.adjust_learning_rate(opt, 200.0, args)
+    seg = E.SegmentedDDPStep(m, ema, opt, args, data[0][ids].cuda(), 200, warmup_iters=0, augment=False, inject_mask_noise=True,
+                             use_graphs=True)
+    seg.static_noise.copy_(noise[0][ids].cuda())
+    bufs = [t.detach().clone() for t in m.buffers()]
+    seg._phase1(data[0][ids].cuda())          # this rank's shard alone, EAGERLY, no collectives
+    seg._phase2()
+    seg._phase3()
+    seg._cut1 = seg._cut2 = seg._cut3 = None
+    with torch.no_grad():
+        for t, v in zip(m.buffers(), bufs):
+            t.copy_(v)
+    torch.cuda.synchronize()
+    g_local = opt.G.detach().cpu().clone()
+    losses, g_avg = [], None
+    for i in range(steps):
+        o = seg(data[i][ids].cuda(), noise[i][ids].cuda())
+        torch.cuda.synchronize()
+        if i == 0:
+            g_avg = opt.G.detach().cpu().clone()
+        losses.append([float(o["loss_chfr"]), float(o["loss_learn"]), float(o["grad_norm"])])
+    both = [torch.empty_like(g_local) for _ in range(world)]
+    dist.all_gather(both, g_local)
+    want = (both[0] + both[1]) / 2
+    torch.save({"avg_equals_mean": bool(torch.equal(g_avg, want)), "max_dev": float((g_avg - want).abs().max()),
+                "shards_differ": not torch.equal(both[0], both[1]), "g_avg_hash": digest(g_avg), "params_hash": digest(opt.P),
+                "ema_hash": digest(opt.E), "losses": losses, "batch_per_rank": B},
+               os.path.join(out, "full_rank%d.pt" % rank))
+    del seg, opt, ema, m
+    torch.cuda.empty_cache()
 
 
 if __name__ == "__main__":

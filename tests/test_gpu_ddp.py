@@ -68,6 +68,20 @@ def test_two_rank_graph_equals_eager(ddp_results):
     assert torch.equal(e0["g_avg"], g0["g_avg"])
 
 
+def test_two_rank_segmented_step_at_the_full_per_rank_batch(ddp_results):
+    """BASELINE config #3's per-rank size (B = 128 clouds per rank) through the captured four-graph step with two ranks (gloo, one GPU):
+    the averaged gradient EQUALS the mean of the two eagerly computed shard gradients, and the replicas' parameters and EMA teacher are
+    bit-identical after 3 steps (compared inside the workers / by SHA-256: the flat buffers are 147 MB each)."""
+    f0, f1 = _load(ddp_results, "full")
+    assert f0["batch_per_rank"] == 128 and f0["shards_differ"]
+    assert f0["avg_equals_mean"] and f1["avg_equals_mean"], (f0["max_dev"], f1["max_dev"])
+    assert f0["g_avg_hash"] == f1["g_avg_hash"]
+    assert f0["params_hash"] == f1["params_hash"] and f0["ema_hash"] == f1["ema_hash"]
+    for a, b in zip(f0["losses"], f1["losses"]):
+        assert all(x == x and abs(x) != float("inf") for x in a + b)
+        assert abs(a[2] - b[2]) <= 1e-6 * abs(a[2])
+
+
 def test_two_rank_train_one_epoch(ddp_results):
     """The drop-in epoch loop (engine_pretrain.train_one_epoch, P/engine_pretrain.py:38-271) with a process group of two ranks: it builds
     its own gradient synchroniser (which broadcasts rank 0's state: the ranks were seeded differently), runs the first iterations
