@@ -405,11 +405,15 @@ _arange_cache = {}
 
 
 def _arange_ids(B, L, device):
-    """(B,L) int64 rows of 0..L-1 (the all-visible id list of the teacher pass), cached per shape."""
+    """(B,L) int64 rows of 0..L-1 (the all-visible id list of the teacher pass), cached per shape; created outside stream capture only
+    (a tensor first made inside a capture lives in the graph's pool and holds nothing until the first replay)."""
     key = (B, L, device.type, device.index)
-    if key not in _arange_cache:
-        _arange_cache[key] = torch.arange(L, device=device).unsqueeze(0).expand(B, L).contiguous()
-    return _arange_cache[key]
+    t = _arange_cache.get(key)
+    if t is None:
+        t = torch.arange(L, device=device).unsqueeze(0).expand(B, L).contiguous()
+        if not (device.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            _arange_cache[key] = t
+    return t
 
 
 _const_cache = {}

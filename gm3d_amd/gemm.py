@@ -458,6 +458,10 @@ def _nt_counter_slice(device, need):
     return buf[off:off + need]
 
 
+from . import streams as _streams_mod  # noqa: E402
+_streams_mod.before_capture(lambda device: _nt_counter_slice(device, 0))   # the counters exist before any audited capture begins
+
+
 def wgrad_nt(dy, x, out=None, splits=None):
     """out (nb,N,K) f32 = dy[b]^T @ x[b]  (dy (nb,R,N), x (nb,R,K) bf16) -- every weight gradient of a block stack in one launch,
     written into `out` (the parameters' slots of the flat gradient buffer) when given.  Long reductions over few output tiles

@@ -249,6 +249,9 @@ def overflow_flag(device):
     return _overflow[key]
 
 
+fused._streams.before_capture(overflow_flag)
+
+
 def partition_visible(masked, Tc):
     """masked (B,T) bool / uint8 (True = masked) -> dict(perm_c, perm_v (B,Tc) int32, inv_v, inv_m (B,T) int32, vis_c (B,Tc) uint8);
     include/gm3d.h gm3d_partition_visible."""

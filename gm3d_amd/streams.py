@@ -62,10 +62,24 @@ def open_streams():
     return list(_ledgers[-1].open.values()) if _ledgers else []
 
 
+_before_capture = []
+
+
+def before_capture(fn):
+    """register fn(device): called by capture() BEFORE the capture begins.  For per-device singletons (flags, counters) that must
+    not be born inside a capture: a tensor first made there lives in the graph's pool and holds nothing until the first replay."""
+    _before_capture.append(fn)
+    return fn
+
+
 @contextlib.contextmanager
 def capture(graph, **kw):
     """torch.cuda.graph(graph, **kw) whose end is audited: RuntimeError (after a rescue join, so that the capture itself ends
     cleanly) when a stream forked inside the body never came back to the capture-origin stream."""
+    if torch.cuda.is_available():
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for fn in _before_capture:
+            fn(dev)
     with torch.cuda.graph(graph, **kw):
         led = _Ledger(torch.cuda.current_stream())
         _ledgers.append(led)
