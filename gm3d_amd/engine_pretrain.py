@@ -238,7 +238,8 @@ class GradSync:
         self._pending = [len(ps) for _, ps in self.buckets]
         self._works = []
         self._launched = [False] * len(self.buckets)
-        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # (one rank: SUM, see SegmentedDDPStep.__init__)
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and self.world > 1
         self.overlap = True   # False: hooks stay silent and finish() issues every bucket (used around captured graphs)
         for p in self.params:
             p.register_post_accumulate_grad_hook(self._hook)
@@ -269,7 +270,8 @@ class GradSync:
         self._flat = G
         self._pending = [len(ps) for _, ps in self.buckets]
         self._works, self._launched = [], [False] * len(self.buckets)
-        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # (one rank: SUM, see SegmentedDDPStep.__init__)
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and self.world > 1
         self.overlap = False          # gradients reach the flat buffer by one gather at the end of backward
         return self
 
@@ -322,7 +324,7 @@ class GradSync:
                 self._launch(b)
         for work, b in self._works:
             work.wait()
-            if not self._avg:
+            if not self._avg and self.world > 1:
                 self.buckets[b][0].div_(self.world)
         # ready for the next step whether or not the caller goes through zero_grad() (the flat path zeroes through the
         # optimizer, and a replayed graph calls nothing at all): every finish() issues one collective per bucket
@@ -711,7 +713,10 @@ class SegmentedDDPStep:
         self.raw = model.module if hasattr(model, "module") else model
         self.group, self.augment = process_group, augment
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # RCCL averages inside its ring kernel (ReduceOp.AVG).  A group of ONE rank keeps SUM: AVG there runs RCCL's one-rank
+        # pre-multiply kernel over the whole range (71 us per collective measured, 0.21 ms per step: tools/seg_timeline.py), which
+        # no N > 1 run executes -- a one-rank rehearsal of the layout should not be charged for it.
+        self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl" and self.world > 1
         self.accum = getattr(args, "accum_iter", 1)
         if broadcast:
             broadcast_state(self.raw, model_ema, optimizer, group=process_group)
@@ -814,8 +819,8 @@ class SegmentedDDPStep:
         p1 = self.seg_params[1]
         outs = [t for t, gt in ((x_vis, gx), (pos_full, gp)) if gt is not None]
         gouts = [gt for gt in (gx, gp) if gt is not None]
-        g = torch.autograd.grad(outs, p1 + [tokens_d, pos_all_d], grad_outputs=gouts, allow_unused=True)   # (no async_wgrad: the
-        # segment's all-reduce follows immediately, there is nothing to run the GEMMs beside)
+        g = torch.autograd.grad(outs, p1 + [tokens_d, pos_all_d], grad_outputs=gouts, allow_unused=True)   # (no fused.async_wgrad
+        # region around a segment: measured 7.98 vs 7.87 ms with one around this one, profiles/NEGATIVE_RESULTS.md round 4)
         self._store(1, g[:len(p1)])
         self._cut3 = (g[len(p1)], g[len(p1) + 1])
 
@@ -843,7 +848,7 @@ class SegmentedDDPStep:
                 continue
             w, buf = item
             w.wait()
-            if not self._avg:
+            if not self._avg and self.world > 1:
                 buf.div_(self.world)
 
     def _run(self, phases, update):

@@ -142,7 +142,13 @@ def full_size_leg(rank, world, out, E, M, clouds, args, B=128, steps=3):
     both = [torch.empty_like(g_local) for _ in range(world)]
     dist.all_gather(both, g_local)
     want = (both[0] + both[1]) / 2
+    offs = list(opt._offs) + [opt.G.numel()]          # a failure names its parameters and segments (diagnosis without a re-run)
+    worst = sorted(((float((g_avg[o:e] - want[o:e]).abs().max()), float(want[o:e].abs().max()), n)
+                    for (n, _), o, e in zip(opt._named, offs[:-1], offs[1:]) if not torch.equal(g_avg[o:e], want[o:e])), reverse=True)
+    seg_equal = {int(k): bool(torch.equal(g_avg[lo:hi], want[lo:hi])) for k, (lo, hi) in opt.segment_ranges.items()}
     torch.save({"avg_equals_mean": bool(torch.equal(g_avg, want)), "max_dev": float((g_avg - want).abs().max()),
+                "worst": worst[:8], "n_differ": len(worst), "segments_equal": seg_equal,
+                "local_equals_avg_here": bool(torch.equal(g_avg, g_local)),
                 "shards_differ": not torch.equal(both[0], both[1]), "g_avg_hash": digest(g_avg), "params_hash": digest(opt.P),
                 "ema_hash": digest(opt.E), "losses": losses, "batch_per_rank": B},
                os.path.join(out, "full_rank%d.pt" % rank))

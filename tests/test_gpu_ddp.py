@@ -74,7 +74,7 @@ def test_two_rank_segmented_step_at_the_full_per_rank_batch(ddp_results):
     bit-identical after 3 steps (compared inside the workers / by SHA-256: the flat buffers are 147 MB each)."""
     f0, f1 = _load(ddp_results, "full")
     assert f0["batch_per_rank"] == 128 and f0["shards_differ"]
-    assert f0["avg_equals_mean"] and f1["avg_equals_mean"], (f0["max_dev"], f1["max_dev"])
+    assert f0["avg_equals_mean"] and f1["avg_equals_mean"], [(f["max_dev"], f["n_differ"], f["segments_equal"], f["worst"]) for f in (f0, f1)]
     assert f0["g_avg_hash"] == f1["g_avg_hash"]
     assert f0["params_hash"] == f1["params_hash"] and f0["ema_hash"] == f1["ema_hash"]
     for a, b in zip(f0["losses"], f1["losses"]):

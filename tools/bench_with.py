@@ -15,6 +15,15 @@ for item in args[:cut]:
         from gm3d_amd._capi import lib
         assert getattr(lib, attr)(int(eval(val))) == 0
         continue
-    setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
+    parts, obj = mod.split("."), None          # engine_pretrain.SegmentedDDPStep._reduce=... : module first, then attributes of it
+    for cutp in range(len(parts), 0, -1):
+        try:
+            obj = importlib.import_module("gm3d_amd." + ".".join(parts[:cutp]))
+        except ImportError:
+            continue
+        for a in parts[cutp:]:
+            obj = getattr(obj, a)
+        break
+    setattr(obj, attr, eval(val))
 sys.argv = [os.path.join(ROOT, "bench.py")] + args[cut + 1:]
 runpy.run_path(sys.argv[0], run_name="__main__")

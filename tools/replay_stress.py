@@ -1,0 +1,100 @@
+"""Do the captured backward graphs of SegmentedDDPStep give the SAME gradient on every replay while another process keeps the GPU busy?
+A missing dependency between parallel branches of a graph survives quiet runs (the timing hides it) and shows as a rare mismatch when the
+card is shared -- as the two-rank tests share it.  One process replays graphs 1-3 (no optimizer step: the parameters stay put) N times at
+B clouds and compares the flat gradient buffer with the eagerly computed one after every replay; a child process runs eager steps of the
+same model beside it for the whole time.
+    python tools/replay_stress.py [B] [replays]          SET="mod.ATTR=val ..." as in tools/seg_b128_diag.py;  LOAD=0: no second process"""
+import os, sys, subprocess, time
+from types import SimpleNamespace
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import torch.distributed as dist
+LOADER = len(sys.argv) > 1 and sys.argv[1] == "--load"
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29658" if LOADER else "29657")
+torch.cuda.set_device(0)
+dist.init_process_group("gloo", rank=0, world_size=1)
+from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
+import importlib
+for item in os.environ.get("SET", "").split():
+    name, val = item.split("=")
+    mod, attr = name.rsplit(".", 1)
+    setattr(importlib.import_module("gm3d_amd." + mod), attr, eval(val))
+    print("set", name, val, flush=True)
+from tests import clouds
+args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
+
+
+def build(B, graphs):
+    data = clouds.gaussian(B, 1024, 900).cuda()
+    noise = torch.rand(B, 64, generator=torch.Generator().manual_seed(950)).cuda()
+    torch.manual_seed(100)
+    m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+    for mod in m.modules():
+        if isinstance(mod, M.DropPath):
+            mod.drop_prob = 0.0
+    ema = E.ModelEma(m, 0.999)
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment)
+    E.adjust_learning_rate(opt, 200.0, args)
+    seg = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=int(os.environ.get("WARM", "0")), augment=False, inject_mask_noise=True,
+                             use_graphs=graphs)
+    seg.static_noise.copy_(noise)
+    return seg, opt, data
+
+
+def eager(seg, data):
+    seg._phase1(data)
+    seg._phase2()
+    seg._phase3()
+    seg._cut1 = seg._cut2 = seg._cut3 = None
+
+
+if LOADER:
+    seg, opt, data = build(int(sys.argv[2]), False)
+    t_end = time.time() + float(sys.argv[3])
+    n = 0
+    while time.time() < t_end:
+        eager(seg, data)
+        torch.cuda.synchronize()
+        n += 1
+    print("loader: %d eager passes" % n, flush=True)
+    sys.exit(0)
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
+seg, opt, data = build(B, True)
+eager(seg, data)
+torch.cuda.synchronize()
+ref = opt.G.detach().clone()
+for g in seg.graphs[:3]:
+    g.replay()
+torch.cuda.synchronize()
+OUT = {k: v.detach().clone() for k, v in seg.out.items() if torch.is_tensor(v)}       # forward results of a quiet replay
+out_bad = {k: 0 for k in OUT}
+child = None
+if os.environ.get("LOAD", "1") == "1":
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--load", str(B), os.environ.get("LOAD_S", "45")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    time.sleep(20)                    # its import + model build
+offs = list(opt._offs) + [opt.G.numel()]
+bad = []
+t0 = time.time()
+for i in range(N):
+    opt.G.zero_() if i % 2 else opt.G.fill_(float("nan"))       # nothing may survive from the previous replay
+    for g in seg.graphs[:3]:
+        g.replay()
+    torch.cuda.synchronize()
+    for k, v in OUT.items():
+        out_bad[k] += int(not torch.equal(seg.out[k], v))
+    if not torch.equal(opt.G, ref):
+        names = [(float((opt.G[o:e] - ref[o:e]).abs().max()), n) for (n, _), o, e in zip(opt._named, offs[:-1], offs[1:]) if not torch.equal(opt.G[o:e], ref[o:e])]
+        bad.append((i, len(names), sorted(names, reverse=True)[:4]))
+    if time.time() - t0 > float(os.environ.get("LOAD_S", "45")) - 22:
+        N = i + 1
+        break
+print("B=%d: %d of %d replays differ from the eager gradient%s" % (B, len(bad), N, "" if child is None else " (second process running beside)"))
+print("forward results that differed from a quiet replay (count of replays):", out_bad)
+for b in bad[:3]:
+    print("  replay %d: %d parameters differ, worst %s" % b)
+if child is not None:
+    out, _ = child.communicate(timeout=120)
+    print(out.decode().strip())

@@ -18,6 +18,22 @@ for item in os.environ.get("SET", "").split():        # SET="fused.ASYNC_WGRAD=F
 from tests import clouds
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 use_graphs = (sys.argv[2] != "eager") if len(sys.argv) > 2 else True
+def poison(gb=24):
+    """freed device memory full of NaN patterns, both in the caching allocator's free blocks and returned to the driver: whatever reads
+    memory it never wrote shows up as NaN / a mismatch instead of passing on a fresh box's zero pages."""
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    a = torch.full((gb << 28,), float("nan"), device="cuda")
+    del a
+    torch.cuda.empty_cache()
+    a = torch.full((gb << 28,), float("nan"), device="cuda")
+    del a
+    torch.cuda.synchronize()
+
+
+POISON = os.environ.get("POISON") == "1"
+if POISON:
+    poison()
 args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
 data = clouds.gaussian(B, 1024, 900).cuda()
 noise = torch.rand(B, 64, generator=torch.Generator().manual_seed(950)).cuda()
@@ -43,6 +59,8 @@ def eager_local():
     torch.cuda.synchronize()
     return opt.G.detach().clone()
 g1 = eager_local()
+if POISON:
+    poison()
 g2 = eager_local()
 print("eager vs eager equal:", torch.equal(g1, g2), float((g1 - g2).abs().max()))
 P0 = opt.P.clone()
