@@ -310,11 +310,14 @@ __global__ __launch_bounds__(256) void attn_qkv_fwd_bf16_kernel(const bf16_t* __
     const int wm = (w >> 1) * 32, wn = (w & 1) * 96;
 #pragma unroll
     for (int s = 0; s < LOOK; ++s) GM3D_QA_STAGE(s)
-    // stage KT_: wait until it has landed (the younger stages in flight may stay out), barrier (everybody is also done with the
-    // buffer stage KT_ + LOOK goes to), refill, multiply
+    // stage KT_: wait until it has landed (the younger stages in flight may stay out) AND until this wave's LDS reads of the stage
+    // before have returned -- lgkmcnt(0): the barrier builtin is no memory fence for the compiler, which otherwise sinks the wait
+    // for the last ds_read of stage KT_ - 1 below the barrier, while the refill issued by a faster wave right behind the barrier
+    // goes to exactly that buffer (tools/kernel_stress.py: 5 of 3000 launches differed under a concurrent load) --, barrier, refill,
+    // multiply
 #define GM3D_QA_ITER(KT_)                                                                                                   \
     {                                                                                                                       \
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * ((QA_KT - 1 - (KT_)) < (LOOK - 1) ? (QA_KT - 1 - (KT_)) : (LOOK - 1))) : "memory"); \
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(8 * ((QA_KT - 1 - (KT_)) < (LOOK - 1) ? (QA_KT - 1 - (KT_)) : (LOOK - 1))) : "memory"); \
         __builtin_amdgcn_s_barrier();                                                                                       \
         if ((KT_) + LOOK < QA_KT) GM3D_QA_STAGE((KT_) + LOOK)                                                               \
         const unsigned char* as = smem + ((KT_) % NBUF) * QA_STAGE;                                                         \

@@ -8,8 +8,15 @@
 // Design (MI355X): one workgroup per cloud; the cloud and its running-min array live
 // in registers for the whole launch (single HBM read, 12 B/point); every one of the
 // npoint-1 dependent steps is  {packed-fp32 register scan -> DPP wave max/argmin ->
-// one LDS key per wave -> one barrier -> 16-lane row reduction}.  No global-memory round trip
-// inside the loop (clouds up to 8192 points keep an LDS copy for the winner's coordinates).
+// one LDS key per wave -> one barrier -> 16-lane row reduction -> the winner's coordinates,
+// 12 bytes re-read from the cloud in global memory (this workgroup loaded it a moment ago: an L2 hit)}.
+// The kernel keeps NO long-lived LDS state: an earlier version held an LDS copy of the cloud for
+// the winner's coordinates (2.6 us faster at 1024 -> 64) and gave a few clouds a wrong sample in
+// 3.5 % of launches whenever ANOTHER PROCESS was running kernels on the same GPU -- as the two-rank
+// tests do.  tools/fps_shared_gpu_probe.py isolated it: every variant that kept the LDS copy failed
+// (DPP or shuffles, one wave or four, one barrier or two), the variant below did not in 111,898
+// launches; with the load coming from a second stream of the SAME process nothing ever failed.
+// Workgroups that live for tens of microseconds are the ones a process switch saves and restores.
 #include "common.hpp"
 
 namespace gm3d {
@@ -65,19 +72,18 @@ __device__ __forceinline__ unsigned long long row_max_u64(unsigned long long k) 
 // workgroup -- so the step is written for instruction count):
 //   scan    PPT points as packed pairs: v_pk_add/v_pk_mul_f32 for ((dx*dx + dy*dy) + dz*dz) (separately rounded,
 //           identical to the scalar contract), v_min + compare/select of (best, index) only -- the winner's
-//           coordinates are NOT carried through the selects, they are re-read from an LDS copy of the cloud;
+//           coordinates are NOT carried through the selects, they are re-read from the cloud (L2);
 //           skipped points (|p|^2 <= 1e-3) carry tmin = -1 and never win, so the scan has no branches;
 //   reduce  wave max of `best` (f32 DPP), then wave min of the index among the lanes that hold it;
 //   publish one 64-bit key per wave, ONE barrier (double-buffered slots), lanes 0..NW-1 of every row re-read the
 //           slots and finish with a 4-step row reduction.
-template <int T, int PPT, bool LDS_CLOUD>
+template <int T, int PPT>
 __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, int N, int npoint,
                                                 int32_t* __restrict__ idx_out,
                                                 float* __restrict__ centers) {
     constexpr int NW = T / GM3D_WAVE;
     static_assert(NW <= 16 && PPT % 2 == 0, "one 16-lane row holds the per-wave keys; points are scanned in pairs");
     __shared__ unsigned long long slots[2][16];
-    extern __shared__ float cloud[];   // [3*N] when LDS_CLOUD
 
     const int b = blockIdx.x;
     const int tid = threadIdx.x;
@@ -97,7 +103,6 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         px[i >> 1][i & 1] = x; py[i >> 1][i & 1] = y; pz[i >> 1][i & 1] = z;
         const float mag = __fadd_rn(__fadd_rn(__fmul_rn(x, x), __fmul_rn(y, y)), __fmul_rn(z, z));
         tmin[i] = (in && mag > 1e-3f) ? 1e10f : -1.0f;
-        if (LDS_CLOUD && in) { cloud[k * 3 + 0] = x; cloud[k * 3 + 1] = y; cloud[k * 3 + 2] = z; }
     }
     if (tid < 32) slots[tid >> 4][tid & 15] = 0ull;
     __syncthreads();
@@ -132,8 +137,7 @@ __global__ __launch_bounds__(T) void fps_kernel(const float* __restrict__ xyz, i
         unsigned long long fk = row_max_u64(slots[j & 1][lane & 15]);     // slots >= NW stay 0
         const unsigned flo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)fk);
         const int old = (__builtin_amdgcn_readfirstlane((int)(unsigned)(fk >> 32)) | (int)flo) != 0 ? (int)(~flo) : 0;
-        if (LDS_CLOUD) { ox = cloud[old * 3 + 0]; oy = cloud[old * 3 + 1]; oz = cloud[old * 3 + 2]; }
-        else { ox = p[(size_t)old * 3 + 0]; oy = p[(size_t)old * 3 + 1]; oz = p[(size_t)old * 3 + 2]; }
+        ox = p[(size_t)old * 3 + 0]; oy = p[(size_t)old * 3 + 1]; oz = p[(size_t)old * 3 + 2];
         if (tid == 0) {
             out[j] = old;
             if (cen) { cen[(size_t)j * 3 + 0] = ox; cen[(size_t)j * 3 + 1] = oy; cen[(size_t)j * 3 + 2] = oz; }
@@ -173,15 +177,7 @@ __global__ void gather_points_grad_kernel(const float* __restrict__ gout, const 
 
 template <int T, int PPT>
 static int launch_fps(const float* xyz, int B, int N, int npoint, int32_t* idx, float* centers, hipStream_t st) {
-    const size_t lds = (size_t)N * 3 * sizeof(float);
-    if (lds <= 100 * 1024) {                // the cloud fits beside the slots: winner coordinates come from LDS
-        if (lds > 48 * 1024 && hipFuncSetAttribute((const void*)fps_kernel<T, PPT, true>,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return GM3D_ELAUNCH;
-        hipLaunchKernelGGL((fps_kernel<T, PPT, true>), dim3(B), dim3(T), lds, st, xyz, N, npoint, idx, centers);
-    } else {
-        hipLaunchKernelGGL((fps_kernel<T, PPT, false>), dim3(B), dim3(T), 0, st, xyz, N, npoint, idx, centers);
-    }
+    hipLaunchKernelGGL((fps_kernel<T, PPT>), dim3(B), dim3(T), 0, st, xyz, N, npoint, idx, centers);
     GM3D_CHECK_LAUNCH();
     return GM3D_OK;
 }

@@ -57,7 +57,7 @@ if os.environ.get("LOAD") == "thread":
                     ops.fps(data, 64)
                     fused._attention_qkv_fwd(h16, wqkv, B, T, H, 0.125)
                 side.synchronize()
-    th = threading.Thread(target=busy, daemon=True)
+    th = threading.Thread(target=busy)
     th.start()
     time.sleep(2)
 elif os.environ.get("LOAD", "1") == "1":
@@ -85,6 +85,8 @@ for i in range(N):
     if child is not None and time.time() - t0 > float(os.environ.get("LOAD_S", "60")) - 24:
         break
 stop.append(1)
+if os.environ.get("LOAD") == "thread":
+    th.join()
 print("%d rounds%s: launches whose output differed from the quiet launch" % (rounds, "" if child is None else " beside a second process"))
 for k in cases:
     print("  %-34s %d   %s" % (k, bad[k], detail.get(k, "")))
