@@ -60,6 +60,80 @@ if LOADER:
     print("loader: %d eager passes" % n, flush=True)
     sys.exit(0)
 
+if len(sys.argv) > 1 and sys.argv[1] == "--m2ae":
+    # the Point-M2AE step as ONE graph with a zero learning rate (parameters and teacher stay put): every replay on the same input and
+    # mask noise must leave the same flat gradient buffer.  LOAD=1 a loader process beside it, LOAD=thread a second stream of this one.
+    from gm3d_amd import point_m2ae as P
+    B, N = 128, int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    pts = clouds.gaussian(B, 2048, seed=900).cuda()
+    noise = torch.rand(B, 64, generator=torch.Generator().manual_seed(40)).cuda()
+    torch.manual_seed(11)
+    m = P.PointM2AE().cuda().train()
+    for mod in m.modules():
+        if hasattr(mod, "drop_prob"):
+            mod.drop_prob = 0.0
+    ema = E.ModelEma(m, 1.0)                        # decay 1: the teacher stays exactly where it is
+    opt = E.build_optimizer(m, lr=0.0, weight_decay=0.0, flat=True, model_ema=ema)
+    a2 = SimpleNamespace(bf16=True, epochs=300)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):
+            P.pretrain_step(m, ema, opt, pts.clone(), 100, a2, mask_noise=noise, augment=False)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            out = P.pretrain_step(m, ema, opt, pts, 100, a2, mask_noise=noise, augment=False)
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    ref, P0, E0 = opt.G.detach().clone(), opt.P.detach().clone(), opt.E.detach().clone()
+    for i in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        print("quiet replay %d equal to the first: %s (teacher unchanged: %s)" % (i + 1, torch.equal(opt.G, ref), torch.equal(opt.E, E0)), flush=True)
+    child, stop = None, []
+    if os.environ.get("LOAD", "1") == "1":
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--load", "128", os.environ.get("LOAD_S", "45")], stdout=subprocess.PIPE,
+                                 stderr=subprocess.DEVNULL)
+        time.sleep(20)
+    elif os.environ.get("LOAD") == "thread":
+        import threading
+        s2 = torch.cuda.Stream()
+        big = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+        seg2, _, d2 = build(64, False)
+
+        def busy():
+            with torch.cuda.stream(s2):
+                while not stop:
+                    for _ in range(4):
+                        (big @ big).relu_()
+                        eager(seg2, d2)
+                    s2.synchronize()
+        th = threading.Thread(target=busy)
+        th.start()
+        time.sleep(2)
+    offs = list(opt._offs) + [opt.G.numel()]
+    bad, t0 = [], time.time()
+    for i in range(N):
+        g.replay()
+        torch.cuda.synchronize()
+        if not torch.equal(opt.G, ref):
+            names = [(float((opt.G[o:e] - ref[o:e]).abs().max()), n) for (n, _), o, e in zip(opt._named, offs[:-1], offs[1:]) if not torch.equal(opt.G[o:e], ref[o:e])]
+            bad.append((i, len(names), sorted(names, reverse=True)[:4]))
+        if time.time() - t0 > 25:
+            N = i + 1
+            break
+    stop.append(1)
+    if os.environ.get("LOAD") == "thread":
+        th.join()
+    print("Point-M2AE B=%d: %d of %d replays differ from the first (load: %s); parameters unchanged: %s" % (B, len(bad), N, os.environ.get("LOAD", "1"),
+                                                                                                      torch.equal(opt.P, P0)))
+    for b in bad[:4]:
+        print("  replay %d: %d parameters differ, worst %s" % b)
+    if child is not None:
+        print(child.communicate(timeout=120)[0].decode().strip())
+    sys.exit(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 seg, opt, data = build(B, True)
