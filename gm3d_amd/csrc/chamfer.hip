@@ -256,6 +256,83 @@ __global__ void chamfer_bwd_general_kernel(const float* __restrict__ A, const fl
     }
 }
 
+// ---- small equal patches (n == m == 8 or 16: the fine patches of Point-M2AE) -----------------------------------------------------
+// SEG lanes per patch (lane l holds point l of both clouds), 64 / SEG patches per wave, partners by width-SEG shuffles.  Forward: both
+// directions in one launch, first minimum wins (j == 0 seeds, strict <, ascending j) like every other form.  Backward: no zero fill and
+// no atomics -- each lane sums its own slot in the order of the sequential loops (direction 1 over ascending i, then direction 2 over
+// ascending j): the general kernel's float atomics made the order a property of the hardware.
+template <int SEG>
+__global__ __launch_bounds__(256) void chamfer_small_fwd_kernel(const float* __restrict__ A, const float* __restrict__ Bp, int P,
+                                                                float* __restrict__ d1, float* __restrict__ d2,
+                                                                int32_t* __restrict__ i1, int32_t* __restrict__ i2) {
+    const int g = blockIdx.x * (256 / SEG) + threadIdx.x / SEG, l = threadIdx.x % SEG;
+    const bool live = g < P;
+    const size_t o = ((size_t)(live ? g : 0) * SEG + l) * 3;
+    const float ax = A[o], ay = A[o + 1], az = A[o + 2], bx = Bp[o], by = Bp[o + 1], bz = Bp[o + 2];
+    float best1 = 0.f, best2 = 0.f;
+    int k1 = 0, k2 = 0;
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+        const float tbx = __shfl(bx, t, SEG), tby = __shfl(by, t, SEG), tbz = __shfl(bz, t, SEG);
+        const float tax = __shfl(ax, t, SEG), tay = __shfl(ay, t, SEG), taz = __shfl(az, t, SEG);
+        const float e1 = sqdist3(ax, ay, az, tbx, tby, tbz), e2 = sqdist3(bx, by, bz, tax, tay, taz);
+        if (t == 0 || e1 < best1) { best1 = e1; k1 = t; }
+        if (t == 0 || e2 < best2) { best2 = e2; k2 = t; }
+    }
+    if (live) {
+        const size_t q = (size_t)g * SEG + l;
+        d1[q] = best1; i1[q] = k1; d2[q] = best2; i2[q] = k2;
+    }
+}
+
+template <int SEG>
+__global__ __launch_bounds__(256) void chamfer_small_bwd_kernel(const float* __restrict__ A, const float* __restrict__ Bp,
+                                                                const int32_t* __restrict__ i1, const int32_t* __restrict__ i2,
+                                                                const float* __restrict__ g1, const float* __restrict__ g2, int P,
+                                                                float* __restrict__ gA, float* __restrict__ gB) {
+    const int g = blockIdx.x * (256 / SEG) + threadIdx.x / SEG, l = threadIdx.x % SEG;
+    const bool live = g < P;
+    const size_t q = (size_t)(live ? g : 0) * SEG + l, o = q * 3;
+    const float a[3] = {A[o], A[o + 1], A[o + 2]}, b[3] = {Bp[o], Bp[o + 1], Bp[o + 2]};
+    const int k1 = i1[q], k2 = i2[q];
+    const float w1 = g1 ? g1[q] : 0.f, w2 = g2 ? g2[q] : 0.f;
+    float t1[3], t2[3];       // this lane's term of direction 1 (point l of A against B[k1]) and of direction 2 (point l of B against A[k2])
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        t1[d] = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(a[d], __shfl(b[d], k1, SEG))), w1);
+        t2[d] = __fmul_rn(__fmul_rn(2.0f, __fsub_rn(b[d], __shfl(a[d], k2, SEG))), w2);
+    }
+    float ra[3] = {0.f, 0.f, 0.f}, rb[3] = {0.f, 0.f, 0.f};
+    // direction 1, ascending i: gA[i] += t1_i ; gB[k1_i] -= t1_i
+#pragma unroll
+    for (int d = 0; d < 3; ++d) ra[d] = __fadd_rn(ra[d], t1[d]);
+#pragma unroll
+    for (int i = 0; i < SEG; ++i) {
+        const bool hit = __shfl(k1, i, SEG) == l;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = __shfl(t1[d], i, SEG);
+            if (hit) rb[d] = __fsub_rn(rb[d], v);
+        }
+    }
+    // direction 2, ascending j: gB[j] += t2_j ; gA[k2_j] -= t2_j
+#pragma unroll
+    for (int d = 0; d < 3; ++d) rb[d] = __fadd_rn(rb[d], t2[d]);
+#pragma unroll
+    for (int j = 0; j < SEG; ++j) {
+        const bool hit = __shfl(k2, j, SEG) == l;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float v = __shfl(t2[d], j, SEG);
+            if (hit) ra[d] = __fsub_rn(ra[d], v);
+        }
+    }
+    if (live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { gA[o + d] = ra[d]; gB[o + d] = rb[d]; }
+    }
+}
+
 }  // namespace gm3d
 
 extern "C" int gm3d_chamfer_fwd(const float* xyz1, const float* xyz2, int P, int n, int m, float* dist1,
@@ -267,6 +344,12 @@ extern "C" int gm3d_chamfer_fwd(const float* xyz1, const float* xyz2, int P, int
     if (n == 32 && m == 32) {
         hipLaunchKernelGGL(chamfer32_fwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, xyz1, xyz2, P, dist1, dist2,
                            idx1, idx2);
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
+    if (n == m && (n == 8 || n == 16)) {
+        if (n == 8) hipLaunchKernelGGL(chamfer_small_fwd_kernel<8>, dim3((P + 31) / 32), dim3(256), 0, st, xyz1, xyz2, P, dist1, dist2, idx1, idx2);
+        else hipLaunchKernelGGL(chamfer_small_fwd_kernel<16>, dim3((P + 15) / 16), dim3(256), 0, st, xyz1, xyz2, P, dist1, dist2, idx1, idx2);
         GM3D_CHECK_LAUNCH();
         return GM3D_OK;
     }
@@ -290,6 +373,14 @@ extern "C" int gm3d_chamfer_bwd(const float* xyz1, const float* xyz2, const int3
     if (n == 32 && m == 32) {
         hipLaunchKernelGGL(chamfer32_bwd_kernel, dim3((P + 3) / 4), dim3(256), 0, st, xyz1, xyz2, idx1, idx2,
                            grad_dist1, grad_dist2, P, gxyz1, gxyz2);
+        GM3D_CHECK_LAUNCH();
+        return GM3D_OK;
+    }
+    if (n == m && (n == 8 || n == 16)) {
+        if (n == 8) hipLaunchKernelGGL(chamfer_small_bwd_kernel<8>, dim3((P + 31) / 32), dim3(256), 0, st, xyz1, xyz2, idx1, idx2, grad_dist1,
+                                       grad_dist2, P, gxyz1, gxyz2);
+        else hipLaunchKernelGGL(chamfer_small_bwd_kernel<16>, dim3((P + 15) / 16), dim3(256), 0, st, xyz1, xyz2, idx1, idx2, grad_dist1,
+                                grad_dist2, P, gxyz1, gxyz2);
         GM3D_CHECK_LAUNCH();
         return GM3D_OK;
     }

@@ -97,7 +97,7 @@ def test_knn_big_cloud(gops, oracle_ops):
     assert torch.equal(idx.cpu(), ri)
 
 
-@pytest.mark.parametrize("P,n,m", [(4992, 32, 32), (7, 32, 32), (5, 50, 70), (2, 1500, 1100), (3, 1, 9)])
+@pytest.mark.parametrize("P,n,m", [(4992, 32, 32), (7, 32, 32), (5, 50, 70), (2, 1500, 1100), (3, 1, 9), (70001, 8, 8), (37, 8, 8), (4099, 16, 16)])
 def test_chamfer_forward_backward(gops, oracle_ops, P, n, m):
     g = torch.Generator().manual_seed(P * 131 + n)
     a = (torch.rand(P, n, 3, generator=g) - 0.5)
@@ -198,12 +198,43 @@ def test_scale_translate_kernel_equals_op_chain():
     assert float(scale.min()) >= 2.0 / 3.0 - 1e-6 and float(scale.max()) <= 1.5 + 1e-6 and float(shift.abs().max()) <= 0.2 + 1e-6
 
 
+@pytest.mark.parametrize("n", [8, 16])
+def test_chamfer_small_patch_backward_is_the_sequential_sum(gops, n):
+    """n == m == 8 / 16 (Point-M2AE's fine patches): the backward has no atomics; every slot is summed in the order of the sequential loops
+    (direction 1 over ascending i, then direction 2 over ascending j), so it EQUALS an fp32 restatement of those loops."""
+    import numpy as np
+    P = 41
+    g = torch.Generator().manual_seed(n)
+    a = torch.rand(P, n, 3, generator=g) - 0.5
+    b = torch.rand(P, n, 3, generator=g) - 0.5
+    b[:, :3] = a[:, :3]                      # ties and many-to-one nearest neighbours
+    b[:, 5] = b[:, 4]
+    w1, w2 = torch.randn(P, n, generator=g), torch.randn(P, n, generator=g)
+    ag, bg = dev(a).requires_grad_(True), dev(b).requires_grad_(True)
+    d1, d2, i1, i2 = gops.chamfer(ag, bg)
+    ((d1 * w1.cuda()).sum() + (d2 * w2.cuda()).sum()).backward()
+    A, B, I1, I2 = a.numpy(), b.numpy(), i1.cpu().numpy(), i2.cpu().numpy()
+    W1, W2 = w1.numpy(), w2.numpy()
+    ga, gb = np.zeros_like(A), np.zeros_like(B)
+    f = np.float32
+    for p in range(P):
+        for i in range(n):
+            t = f(f(f(2.0) * f(A[p, i] - B[p, I1[p, i]])) * W1[p, i])
+            ga[p, i] = f(ga[p, i] + t)
+            gb[p, I1[p, i]] = f(gb[p, I1[p, i]] - t)
+        for j in range(n):
+            t = f(f(f(2.0) * f(B[p, j] - A[p, I2[p, j]])) * W2[p, j])
+            gb[p, j] = f(gb[p, j] + t)
+            ga[p, I2[p, j]] = f(ga[p, I2[p, j]] - t)
+    assert np.array_equal(ag.grad.cpu().numpy(), ga) and np.array_equal(bg.grad.cpu().numpy(), gb)
+
+
 def test_chamfer_general_backward_survives_graph_replay(gops):
-    """The general-shape Chamfer backward (the 8-point patches of Point-M2AE) zero-fills its outputs before an atomic scatter.  With
+    """The general-shape Chamfer backward (any patch size without a kernel of its own) zero-fills its outputs before an atomic scatter.  With
     hipMemsetAsync as the fill, a captured graph came back with 1e34-sized garbage once the process had made other host-to-device
     copies after the capture (found by tools/m2ae_graph_diag.py): the fill is a kernel of the C ABI now.  Replay after such copies
     must equal the eager result bit for bit (the atomics add one term per slot and direction: order cannot matter)."""
-    P, n = 4096, 8
+    P, n = 4096, 12
     g = torch.Generator().manual_seed(3)
     a = torch.randn(P, n, 3, generator=g).cuda().requires_grad_(True)
     b = torch.randn(P, n, 3, generator=g).cuda()
