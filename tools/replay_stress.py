@@ -51,9 +51,13 @@ def eager(seg, data):
 
 if LOADER:
     seg, opt, data = build(int(sys.argv[2]), False)
+    eager(seg, data)
+    torch.cuda.synchronize()
+    if os.environ.get("READY_FILE"):          # tests wait for this before they start comparing
+        open(os.environ["READY_FILE"], "w").write("ready")
     t_end = time.time() + float(sys.argv[3])
     n = 0
-    while time.time() < t_end:
+    while time.time() < t_end and not (os.environ.get("STOP_FILE") and os.path.exists(os.environ["STOP_FILE"])):
         eager(seg, data)
         torch.cuda.synchronize()
         n += 1
