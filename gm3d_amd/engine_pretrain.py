@@ -174,9 +174,20 @@ class ModelEma:
                 self._int_flat, ie, im = (E, Mv), [], []
         self._pairs = (fe, fm, ie, im)
 
+    def prepare(self, model):
+        """settle the (teacher, student) buffer pairs before anything is captured (FlatAdamWEma's constructor calls this)"""
+        if self._pairs is None:
+            self._build(model)
+
     @torch.no_grad()
     def update(self, model):
         if self._pairs is None:
+            # _build re-points the BatchNorm counters of BOTH models into one stacked tensor.  Inside a capture that is too late: graphs
+            # captured earlier (the forward's counter increments) keep the old addresses, the old tensors are freed, and every replay
+            # then adds 1 to whatever the allocator put there next (found in round 4 as a cloned loss growing by one ulp per replay).
+            if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("ModelEma.update() first called inside a hipGraph capture: call model_ema.prepare(model) (or run one "
+                                   "eager step) before capturing")
             self._build(model)
         fe, fm, ie, im = self._pairs
         if fe:

@@ -136,6 +136,10 @@ class FlatAdamWEma(torch.optim.Optimizer):
                 self.ES.copy_(self.E)
             model_ema.params_in_optimizer = True
             model_ema._pairs = None
+            if hasattr(model_ema, "prepare"):
+                # the teacher's buffer pairs (and the re-pointing of the BatchNorm counters into one tensor) are settled NOW: a step
+                # captured later must not find them unbuilt (ModelEma.update refuses to build inside a capture)
+                model_ema.prepare(model)
         self.LS = None
         if lr_scale_of is not None:
             self.LS = torch.ones(self.n, **f32)

@@ -345,3 +345,58 @@ def test_flat_gradsync_all_reduces_on_every_step(monkeypatch):
         assert len(calls) == nb * (step + 1), (step, len(calls))
     torch.cuda.synchronize()
     assert sum(calls[:nb]) == opt.G.numel()
+
+
+@pytest.mark.parametrize("kind", ["single", "segmented"])
+def test_replays_write_nothing_outside_the_graphs_memory(kind):
+    """Captured with NO eager warm-up (the first execution of the model is the capture itself), then replayed: memory the allocator hands
+    out after the capture must stay as the test fills it.  Round 4: ModelEma settled its buffer pairs on the first update() -- inside
+    the capture of the optimizer graph when nothing had run eagerly -- re-pointing the BatchNorm counters the forward graph had already
+    captured; the freed counters' addresses went to the next small allocation and every replay added 1 there (a cloned loss grew by one
+    ulp per replay).  The pairs are settled at optimizer construction now, and update() refuses to settle them inside a capture."""
+    from types import SimpleNamespace
+    from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
+    from tests import clouds
+    args = SimpleNamespace(mask_ratio=0.6, epochs=400, relative=True, bf16=True, accum_iter=1, lr=2e-4, min_lr=0.0, warmup_epochs=40)
+    # B = 32: every product of the step runs on a kernel of our own.  (At B <= 16 the weight gradients fall back to torch.bmm, and the
+    # BLAS library cannot meet a new problem shape inside a capture: hipBLASLt ends the process with exit code 1.  Steps built with
+    # their default warmup_iters meet every shape eagerly first.)
+    data = clouds.gaussian(32, 1024, 77).cuda()
+    torch.manual_seed(5)
+    m = M.mae_vit_base_patch16_dec512d8b().cuda().train()
+    for mod in m.modules():          # (DropPath's keep-probability table is a host-to-device copy on first use: not inside a capture)
+        if isinstance(mod, M.DropPath):
+            mod.drop_prob = 0.0
+    ema = E.ModelEma(m, 0.999)
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment if kind == "segmented" else None)
+    assert ema._pairs is not None                      # settled by the optimizer's constructor
+    E.adjust_learning_rate(opt, 200.0, args)
+    if kind == "segmented":
+        step = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, broadcast=False)
+    else:
+        step = E.GraphedPretrainStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False)
+    torch.cuda.synchronize()
+    # small and large blocks of every size class the step itself uses, filled with a sentinel
+    guards = [torch.full((n,), 12345.0, device="cuda") for n in (1, 2, 3, 8, 64, 128, 1024) for _ in range(64)]
+    guards += [torch.full((1 << 20,), 12345.0, device="cuda") for _ in range(8)]
+    ints = [torch.full((), 777, dtype=torch.int64, device="cuda") for _ in range(256)]
+    for _ in range(3):
+        out = step(data)
+    torch.cuda.synchronize()
+    assert all(bool((g == 12345.0).all()) for g in guards)
+    assert all(int(t) == 777 for t in ints)
+    assert float(out["loss"]) == float(out["loss"])
+
+
+def test_model_ema_refuses_to_settle_its_pairs_inside_a_capture():
+    from gm3d_amd import engine_pretrain as E
+    net = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8)).cuda()
+    ema = E.ModelEma(net, 0.99)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(RuntimeError, match="prepare"):
+        with torch.cuda.graph(g, stream=side):
+            ema.update(net)
+    ema.prepare(net)
+    ema.update(net)            # eager: fine

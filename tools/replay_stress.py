@@ -16,6 +16,8 @@ torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=0, world_size=1)
 from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
 import importlib
+if os.environ.get("DEBUG_OUT"):
+    torch.cuda.memory._record_memory_history(max_entries=400000)
 for item in os.environ.get("SET", "").split():
     name, val = item.split("=")
     mod, attr = name.rsplit(".", 1)
@@ -149,10 +151,46 @@ for g in seg.graphs[:3]:
 torch.cuda.synchronize()
 OUT = {k: v.detach().clone() for k, v in seg.out.items() if torch.is_tensor(v)}       # forward results of a quiet replay
 out_bad = {k: 0 for k in OUT}
-child = None
+if os.environ.get("DEBUG_OUT"):
+    torch.cuda.synchronize()
+    w = OUT["loss_chfr"]
+    print("clone of loss_chfr right after it was made: %.10f at %d (source %.10f at %d)" % (float(w), w.data_ptr(), float(seg.out["loss_chfr"]), seg.out["loss_chfr"].data_ptr()))
+    for gi, g in enumerate(seg.graphs[:3]):
+        g.replay()
+        torch.cuda.synchronize()
+        print("  after replaying graph %d the clone holds %.10f" % (gi, float(w)))
+    opt.G.zero_(); torch.cuda.synchronize()
+    print("  after G.zero_ the clone holds %.10f" % float(w))
+    A = w.data_ptr()
+    snap = torch.cuda.memory._snapshot()
+    for ev in snap["device_traces"][0]:
+        if ev.get("addr") is not None and ev["addr"] <= A < ev["addr"] + max(ev.get("size", 0), 1) and ev["action"] in ("alloc", "free_requested", "free_completed"):
+            fr = [f for f in ev.get("frames", []) if "/gm3d_amd/" in f["filename"] or "/tools/" in f["filename"]]
+            print("   %-15s addr %d size %d stream %s  %s" % (ev["action"], ev["addr"], ev["size"], ev.get("stream"),
+                                                        " <- ".join("%s:%d" % (os.path.basename(f["filename"]), f["line"]) for f in fr[:5])))
+    for seg_ in snap["segments"]:
+        if seg_["address"] <= A < seg_["address"] + seg_["total_size"]:
+            print("   segment at %d size %d pool %s stream %s" % (seg_["address"], seg_["total_size"], seg_.get("segment_pool_id"), seg_.get("stream")))
+child, stop, th = None, [], None
 if os.environ.get("LOAD", "1") == "1":
     child = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--load", str(B), os.environ.get("LOAD_S", "45")], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
     time.sleep(20)                    # its import + model build
+elif os.environ.get("LOAD") == "thread":          # the load from a second stream of THIS process: eager passes of a twin model + big products
+    import threading
+    s2 = torch.cuda.Stream()
+    big = torch.randn(4096, 4096, device="cuda", dtype=torch.bfloat16)
+    seg2, _, d2 = build(64, False)
+
+    def busy():
+        with torch.cuda.stream(s2):
+            while not stop:
+                for _ in range(4):
+                    (big @ big).relu_()
+                    eager(seg2, d2)
+                s2.synchronize()
+    th = threading.Thread(target=busy)
+    th.start()
+    time.sleep(2)
 offs = list(opt._offs) + [opt.G.numel()]
 bad = []
 t0 = time.time()
@@ -169,8 +207,21 @@ for i in range(N):
     if time.time() - t0 > float(os.environ.get("LOAD_S", "45")) - 22:
         N = i + 1
         break
-print("B=%d: %d of %d replays differ from the eager gradient%s" % (B, len(bad), N, "" if child is None else " (second process running beside)"))
+stop.append(1)
+if th is not None:
+    th.join()
+print("B=%d: %d of %d replays differ from the eager gradient%s" % (B, len(bad), N, " (load: %s)" % os.environ.get("LOAD", "1")))
 print("forward results that differed from a quiet replay (count of replays):", out_bad)
+if os.environ.get("DEBUG_OUT"):
+    for gi, g in enumerate(seg.graphs[:4]):
+        g.replay()
+        torch.cuda.synchronize()
+        a = seg.out["loss"].clone(); b = seg.out["loss_chfr"].clone(); c = seg.out["loss"].clone()
+        torch.cuda.synchronize()
+        print("after graph %d: loss %.10f  loss_chfr %.10f  loss again %.10f  item() %.10f %.10f" % (gi, float(a), float(b), float(c), seg.out["loss"].item(), seg.out["loss_chfr"].item()))
+    for k in OUT:
+        a, b = seg.out[k], OUT[k]
+        print(k, a.dtype, tuple(a.shape), a.data_ptr(), a.flatten()[:2].tolist(), "| quiet", b.flatten()[:2].tolist())
 for b in bad[:3]:
     print("  replay %d: %d parameters differ, worst %s" % b)
 if child is not None:
