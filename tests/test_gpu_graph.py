@@ -367,25 +367,36 @@ def test_replays_write_nothing_outside_the_graphs_memory(kind):
     for mod in m.modules():          # (DropPath's keep-probability table is a host-to-device copy on first use: not inside a capture)
         if isinstance(mod, M.DropPath):
             mod.drop_prob = 0.0
-    ema = E.ModelEma(m, 0.999)
-    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, segment_of=E.ddp_segment if kind == "segmented" else None)
+    ema = E.ModelEma(m, 1.0)                            # decay 1 and (below) learning rate 0: parameters and teacher stay put, so every
+    opt = E.build_optimizer(m, lr=2e-4, flat=True, model_ema=ema, weight_decay=0.0,     # replay must leave the same gradient buffer
+                            segment_of=E.ddp_segment if kind == "segmented" else None)
     assert ema._pairs is not None                      # settled by the optimizer's constructor
+    args.lr = 0.0
     E.adjust_learning_rate(opt, 200.0, args)
     if kind == "segmented":
-        step = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, broadcast=False)
+        step = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, broadcast=False, inject_mask_noise=True)
     else:
-        step = E.GraphedPretrainStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False)
+        step = E.GraphedPretrainStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, inject_mask_noise=True)
+    noise = torch.rand(32, 64, generator=torch.Generator().manual_seed(3)).cuda()
+    step(data, noise)
     torch.cuda.synchronize()
-    # small and large blocks of every size class the step itself uses, filled with a sentinel
+    g1, p1 = opt.G.clone(), opt.P.clone()
+    # (a) stray WRITES: small and large blocks of the size classes the step itself uses, filled with a sentinel
     guards = [torch.full((n,), 12345.0, device="cuda") for n in (1, 2, 3, 8, 64, 128, 1024) for _ in range(64)]
     guards += [torch.full((1 << 20,), 12345.0, device="cuda") for _ in range(8)]
     ints = [torch.full((), 777, dtype=torch.int64, device="cuda") for _ in range(256)]
+    # (b) stray READS: whatever else the allocator still holds free goes to NaN-filled blocks -- a replay that reads memory freed since
+    # the capture now reads NaN instead of stale but plausible values
+    poison = [torch.full((n,), float("nan"), device="cuda") for n in (1, 4, 16, 96, 384, 1536, 1 << 14, 1 << 18) for _ in range(128)]
+    poison += [torch.full((1 << 24,), float("nan"), device="cuda") for _ in range(8)]
     for _ in range(3):
-        out = step(data)
+        out = step(data, noise)
     torch.cuda.synchronize()
     assert all(bool((g == 12345.0).all()) for g in guards)
     assert all(int(t) == 777 for t in ints)
+    assert torch.equal(opt.P, p1) and torch.equal(opt.G, g1)
     assert float(out["loss"]) == float(out["loss"])
+    del poison
 
 
 def test_model_ema_refuses_to_settle_its_pairs_inside_a_capture():
