@@ -347,9 +347,11 @@ def test_flat_gradsync_all_reduces_on_every_step(monkeypatch):
     assert sum(calls[:nb]) == opt.G.numel()
 
 
+@pytest.mark.parametrize("warm", [0, 3])
 @pytest.mark.parametrize("kind", ["single", "segmented"])
-def test_replays_write_nothing_outside_the_graphs_memory(kind):
-    """Captured with NO eager warm-up (the first execution of the model is the capture itself), then replayed: memory the allocator hands
+def test_replays_write_nothing_outside_the_graphs_memory(kind, warm):
+    """Captured with NO eager warm-up (the first execution of the model is the capture itself) or after the production's three eager
+    iterations, then replayed: memory the allocator hands
     out after the capture must stay as the test fills it.  Round 4: ModelEma settled its buffer pairs on the first update() -- inside
     the capture of the optimizer graph when nothing had run eagerly -- re-pointing the BatchNorm counters the forward graph had already
     captured; the freed counters' addresses went to the next small allocation and every replay added 1 there (a cloned loss grew by one
@@ -374,9 +376,9 @@ def test_replays_write_nothing_outside_the_graphs_memory(kind):
     args.lr = 0.0
     E.adjust_learning_rate(opt, 200.0, args)
     if kind == "segmented":
-        step = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, broadcast=False, inject_mask_noise=True)
+        step = E.SegmentedDDPStep(m, ema, opt, args, data, 200, warmup_iters=warm, augment=False, broadcast=False, inject_mask_noise=True)
     else:
-        step = E.GraphedPretrainStep(m, ema, opt, args, data, 200, warmup_iters=0, augment=False, inject_mask_noise=True)
+        step = E.GraphedPretrainStep(m, ema, opt, args, data, 200, warmup_iters=warm, augment=False, inject_mask_noise=True)
     noise = torch.rand(32, 64, generator=torch.Generator().manual_seed(3)).cuda()
     step(data, noise)
     torch.cuda.synchronize()

@@ -192,6 +192,10 @@ def test_m2ae_step_replays_like_eager_at_full_batch():
         with torch.cuda.graph(g, stream=side):
             out = P.pretrain_step(mb, eb, ob, static_in, 100, args, mask_noise=static_noise, augment=False)
     torch.cuda.current_stream().wait_stream(side)
+    # what the allocator hands out after the capture: sentinels (a replay must not write there) and NaN blocks (nor read there)
+    guards = [torch.full((n,), 12345.0, device="cuda") for n in (1, 2, 8, 64, 1024, 1 << 18) for _ in range(64)]
+    ints = [torch.full((), 777, dtype=torch.int64, device="cuda") for _ in range(128)]
+    poison = [torch.full((n,), float("nan"), device="cuda") for n in (1, 4, 16, 96, 384, 1536, 1 << 14, 1 << 20) for _ in range(64)]
     for i in range(2, 5):
         want = P.pretrain_step(ma, ea, oa, pool[i].clone(), 100, args, mask_noise=noise[i], augment=False)
         static_in.copy_(pool[i])
@@ -204,6 +208,8 @@ def test_m2ae_step_replays_like_eager_at_full_batch():
             assert a == b, (i, k, a, b)
         assert bool(torch.isfinite(ob.P).all()) and bool(torch.isfinite(ob.E).all())
     assert torch.equal(oa.P, ob.P) and torch.equal(oa.E, ob.E)
+    assert all(bool((g == 12345.0).all()) for g in guards) and all(int(t) == 777 for t in ints)
+    del poison
     assert int(out["vis_overflow"]) == 0          # the static bounds of the visible-first order held on every replayed batch
 
 
