@@ -473,13 +473,16 @@ def main():
     ap.add_argument("--launch-dry-run", action="store_true",
                     help="start the ranks exactly as a real run would, but each only joins a gloo group, all-reduces its rank "
                          "number and exits (no GPU, no kernels): the CPU test of the launch path")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="NOT a measurement: N ranks over gloo, all of them on GPU 0 -- runs the whole N > 1 code path (rank launch, "
+                         "segmented step, collectives, aggregation of the line) on a one-GPU box; the line carries \"rehearsal\"")
     args = ap.parse_args()
 
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # no launcher above us: be the launcher (before any GPU call)
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.launch_dry_run))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], dry_run=args.launch_dry_run or args.rehearse_gloo))
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -488,6 +491,8 @@ def main():
         sys.exit("bench.py: --gpus %d disagrees with WORLD_SIZE %d" % (args.gpus, world))
     if args.launch_dry_run:
         return dry_run_rank(rank, world)
+    if args.rehearse_gloo:
+        local_rank = 0                      # every rank on GPU 0 (RCCL refuses that: gloo carries the collectives)
     if local_rank >= torch.cuda.device_count():
         sys.exit("bench.py: LOCAL_RANK %d but %d GPU(s) visible" % (local_rank, torch.cuda.device_count()))
     # GM3D_FORCE_DIST=1: take the data-parallel code path (RCCL process group, bucketed all-reduce, two graphs) with a
@@ -498,7 +503,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.cuda.set_device(local_rank)
         with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            if args.rehearse_gloo:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
     else:
@@ -654,7 +662,7 @@ def main():
             "value": args.batch * world * args.steps / dt,
             "unit": "clouds/s",
             "n_gpus": world,
-            "rccl_ranks": dist.get_world_size() if use_dist else None,      # the process group's own count (None: no group, one GPU)
+            "rccl_ranks": dist.get_world_size() if use_dist and not args.rehearse_gloo else None,   # the RCCL group's own count (None: no group, one GPU)
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -684,6 +692,9 @@ def main():
             "hip_kernels_ms_per_step": per_step,
             "loss": loss,
         }
+        if args.rehearse_gloo:
+            line["rehearsal"] = ("%d gloo ranks sharing GPU 0: the N > 1 code path end to end, NOT a measurement "
+                                 "(value is meaningless)" % dist.get_world_size())
         if not args.no_secondary and not use_dist and not args.fp32:
             line["secondary"] = secondary(device)
         # N=1 only: at N>1 the other ranks would sit in a GPU barrier while rank 0 does 20 s of host work

@@ -92,3 +92,24 @@ def test_two_rank_train_one_epoch(ddp_results):
         assert st["replayed_iters"] == 7 - 3 and st["capture_s"] > 0
         assert all(v == v and abs(v) != float("inf") for v in st.values())
     assert abs(e0["stats"]["loss"] - e1["stats"]["loss"]) <= 1e-6 * abs(e0["stats"]["loss"])      # the epoch's metric all-reduce
+
+
+def test_bench_n2_code_path_end_to_end_over_gloo():
+    """`python bench.py --gpus 2 --rehearse-gloo`: the launcher starts two ranks, both on this GPU, gloo carries the collectives -- everything
+    else is the N > 1 bench path the driver's 8-GPU node runs (state broadcast, eager probe through GradSync, the captured four-graph step
+    with its three collectives per step, the agreement all-reduces, MAX over ranks of the timed region, rank 0's line).  Not a measurement:
+    the line says so."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse-gloo", "--batch", "32", "--steps", "3",
+                        "--warmup", "2", "--no-secondary", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] is None and "rehearsal" in d and d["rehearsal"].startswith("2 gloo ranks")
+    assert d["config"]["global_batch"] == 64 and d["config"]["parallelism"] == "dp2" and d["scaling"] == "weak"
+    assert "4 graphs" in d["execution"], d["execution"]
+    assert d["loss"] == d["loss"] and d["value"] > 0 and d["cpu_baseline"] is None
