@@ -245,8 +245,14 @@ def test_graph_replay_equals_eager(M):
                                  augment=False)
             step = lambda x: EF.finetune_step(pm, crit, opt, x, targets, npoints=1024, max_norm=10.0, bf16=False,
                                               subset=rng.choice(1200, 1024, False), augment=False)
+        # what the allocator hands out now: sentinels (a replay must not write there) and NaN blocks (nor read there)
+        guards = [torch.full((n,), 12345.0, device="cuda") for n in (1, 2, 8, 64, 1024, 1 << 18) for _ in range(64)] if graphed else []
+        ints = [torch.full((), 777, dtype=torch.int64, device="cuda") for _ in range(128)] if graphed else []
+        poison = [torch.full((n,), float("nan"), device="cuda") for n in (1, 4, 16, 96, 384, 1536, 1 << 14, 1 << 20) for _ in range(64)] if graphed else []
         for x in batches:
             losses.append(float(step(x)["loss"]))
+        assert all(bool((t == 12345.0).all()) for t in guards) and all(int(t) == 777 for t in ints)
+        del poison
         return losses, {k: v.detach().clone() for k, v in pm.named_parameters()}
 
     le, pe = run(False)

@@ -198,10 +198,16 @@ def test_bf16_graph_replay_matches_eager(M):
         le.append(float(o["loss"] + o["loss_learn"]))
     pe = {k: v.clone() for k, v in pm.state_dict().items()}
     restore()
+    # what the allocator hands out now: sentinels (a replay must not write there) and NaN blocks (nor read there)
+    guards = [torch.full((n,), 12345.0, device="cuda") for n in (1, 2, 8, 64, 1024, 1 << 18) for _ in range(64)]
+    ints = [torch.full((), 777, dtype=torch.int64, device="cuda") for _ in range(128)]
+    poison = [torch.full((n,), float("nan"), device="cuda") for n in (1, 4, 16, 96, 384, 1536, 1 << 14, 1 << 20) for _ in range(64)]
     lg = []
     for xi, ni in zip(x, noise):
         o = g(xi, mask_noise=ni)
         lg.append(float(o["loss"] + o["loss_learn"]))
+    assert all(bool((t == 12345.0).all()) for t in guards) and all(int(t) == 777 for t in ints)
+    del poison
     assert all(np.isfinite(le)) and le == lg, (le, lg)             # exact: deterministic kernels, same operands
     assert all(torch.equal(pm.state_dict()[k], pe[k]) for k in pe)
 
