@@ -91,12 +91,24 @@ class _WeightCache:
         key = (w.data_ptr(), dtype, tuple(w.shape))
         hit = self._c.get(key)
         if hit is not None and hit[0] == w._version and hit[2]() is w:   # same live tensor, unchanged since the cast
+            if w.is_cuda:
+                # the cast may have been launched on ANOTHER stream a moment ago (the parallel inference chains of run_stack meet the
+                # same weights one after the other): whoever reuses it waits for the casting launch and keeps the allocator informed
+                cur = torch.cuda.current_stream(w.device)
+                if hit[3] != cur.cuda_stream:
+                    cur.wait_event(hit[4])
+                    hit[1].record_stream(cur)
             return hit[1]
         with torch.no_grad():
             c = w.detach().to(dtype)
         if len(self._c) > 4096:
             self._c.clear()
-        self._c[key] = (w._version, c, weakref.ref(w))
+        stream_id, done = None, None
+        if w.is_cuda:
+            cur = torch.cuda.current_stream(w.device)
+            stream_id, done = cur.cuda_stream, torch.cuda.Event()
+            done.record(cur)
+        self._c[key] = (w._version, c, weakref.ref(w), stream_id, done)
         return c
 
 

@@ -107,3 +107,26 @@ def test_unjoined_side_stream_in_the_step_capture_raises_and_the_process_lives()
     torch.cuda.synchronize()
     assert float(o["loss"]) == float(o["loss"])
     assert S.open_streams() == []
+
+
+@pytest.mark.gpu
+def test_a_cached_weight_cast_is_waited_for_across_streams():
+    """fused.weight_cache.get casts a weight once and hands the copy to whoever asks next.  The parallel inference chains of run_stack ask
+    from DIFFERENT streams a few microseconds apart: the second one must wait for the casting launch (round 4: the teacher's forward as
+    two chains differed from the single chain once in a full test run beside a loader process -- eager mode with un-pinned weights)."""
+    import torch
+    from gm3d_amd import fused
+    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    w = torch.randn(2048, 2048, device="cuda")
+    big = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(a):
+        for _ in range(20):                       # keeps stream a busy: the cast below is queued behind ~100 ms of products
+            big = big @ big * 1e-4
+        c1 = fused.weight_cache.get(w, torch.bfloat16)
+    with torch.cuda.stream(b):                    # no dependency on stream a except through the cache
+        c2 = fused.weight_cache.get(w, torch.bfloat16)
+        got = c2.float().abs().sum()
+    torch.cuda.synchronize()
+    assert c2 is c1
+    assert float(got) == float(w.bfloat16().float().abs().sum())
