@@ -11,7 +11,16 @@ sys.path.insert(0, ROOT)
 import torch
 import torch.distributed as dist
 LOADER = len(sys.argv) > 1 and sys.argv[1] == "--load"
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29658" if LOADER else "29657")
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))       # (several loaders / stress runs may share a box)
 torch.cuda.set_device(0)
 dist.init_process_group("gloo", rank=0, world_size=1)
 from gm3d_amd import engine_pretrain as E, models_mae_learn_loss as M
