@@ -21,6 +21,11 @@ def short(name):
     return name[:120]
 
 
+FULL = "--full-names" in sys.argv          # keep the template arguments: one row per kernel INSTANCE and grid (diagnosis; bench.py reads the short form)
+if FULL:
+    sys.argv.remove("--full-names")
+    _short = short
+    short = lambda name: re.sub(r"\(.*", "", re.sub(r"^void ", "", name))[:100] if name.startswith(("void gm3d", "gm3d")) else _short(name)
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for d in sys.argv[1:]:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
